@@ -1,0 +1,199 @@
+/* include/weasal_hip.h -- C ABI of libweasal_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary of the KPConv hot path: plain pointers and sizes, no
+ * torch / numpy / C++ types.  Every pointer is a DEVICE pointer unless the parameter
+ * name starts with `h_` (host).  `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  All functions are asynchronous on `stream` unless documented
+ * otherwise, never allocate device memory unless documented, and return a ws_status.
+ *
+ * Each entry names the reference interface it replaces (paths relative to the reference
+ * repository JohannesErnst/WeaSAL).  INTEGRATION.md shows the Python-side bindings.
+ */
+#ifndef WEASAL_HIP_H
+#define WEASAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    WS_OK = 0,
+    WS_ERR_INVALID = 1,      /* bad shape / NULL pointer / inconsistent sizes          */
+    WS_ERR_UNSUPPORTED = 2,  /* valid request this build has no kernel for             */
+    WS_ERR_HIP = 3,          /* a HIP runtime call failed (see ws_last_error)          */
+    WS_ERR_EMPTY = 4,        /* empty result: the reference raises RuntimeError("Error")
+                                (cpp_wrappers/cpp_neighbors/wrapper.cpp:201-205,
+                                 cpp_wrappers/cpp_subsampling/wrapper.cpp:266-270)     */
+    WS_ERR_CAPACITY = 5      /* a caller-provided buffer is too small                  */
+} ws_status;
+
+/* KP_influence / aggregation_mode of models/blocks.py:147 */
+enum { WS_INFLUENCE_LINEAR = 0, WS_INFLUENCE_CONSTANT = 1, WS_INFLUENCE_GAUSSIAN = 2 };
+enum { WS_AGGREGATION_SUM = 0, WS_AGGREGATION_CLOSEST = 1 };
+
+const char* ws_last_error(void);   /* thread-local message of the last failing call */
+const char* ws_version(void);
+int ws_device_count(void);         /* number of HIP devices visible (no context is created) */
+
+/* ------------------------------------------------------------------------------------------
+ * KPConv (models/blocks.py:238-374).
+ *
+ * Shapes:  q_pts [nq,3] f32, s_pts [ns,3] f32, inds [nq,h] int64 with values in [0,ns]
+ * (ns = shadow neighbour: point (1e6,1e6,1e6), zero feature, blocks.py:278,357),
+ * x [ns,ci] f32, kernel_points [k,3] f32.
+ *
+ * ws_kpconv_gather_fwd: the fused neighbour-gather -> kernel-point influence -> feature
+ *   aggregate (blocks.py:278-363):   wf[q,kk,c] = sum_h w(q,h,kk) * x[inds[q,h], c]
+ *   with w = clamp(1 - sqrt(d2)/extent, 0) (linear, :337), 1 (constant, :332) or
+ *   exp(-d2 / (2 (0.3 extent)^2 + 1e-9)) (gaussian, :343 and :70-77); aggregation CLOSEST
+ *   keeps only the arg-min kernel point of each neighbour (:349-351).
+ *   wf is [nq, k, ci] row-major, so that  out = wf.reshape(nq, k*ci) @ weights.reshape(k*ci, co)
+ *   is the dense contraction of blocks.py:370-374 (done by the caller on MFMA).
+ *   Deformable variant (blocks.py:244-325): deformed_kp [nq,k,3] (= kernel_points + offsets,
+ *   :288) replaces kernel_points when non-NULL; neighbours with no kernel point within
+ *   `extent` contribute nothing (:301-325); min_d2 [nq,k] (:304) is written when non-NULL;
+ *   modulations [nq,k] (:256,:367) scale wf[q,kk,:] when non-NULL.
+ * ws_kpconv_gather_bwd_x: dx[s,c] = sum over (q,h) with inds[q,h]==s of
+ *   sum_kk w(q,h,kk) * (mod[q,kk]) * dwf[q,kk,c]   -- the autograd of the gather
+ *   (a scatter_add in the reference), computed as a deterministic gather over the transposed
+ *   neighbour table built by ws_transpose_build.
+ * ws_kpconv_gather_bwd_geom (deformable only): gradients w.r.t. deformed_kp [nq,k,3] and
+ *   modulations [nq,k], from dwf and from d(min_d2).
+ * ------------------------------------------------------------------------------------------ */
+int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                         const int64_t* inds, int32_t h,
+                         const float* x, int32_t ci,
+                         const float* kernel_points, int32_t k,
+                         const float* deformed_kp,    /* NULL = rigid */
+                         const float* modulations,    /* NULL = none  */
+                         float extent, int32_t influence, int32_t aggregation,
+                         float* wf,                   /* out [nq,k,ci] */
+                         float* min_d2,               /* out [nq,k] or NULL */
+                         void* stream);
+
+int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                           const int64_t* inds, int32_t h,
+                           const int32_t* t_offsets,  /* [ns+2] from ws_transpose_build */
+                           const int32_t* t_pairs,    /* [nq*h]  from ws_transpose_build */
+                           const float* dwf, int32_t ci,      /* [nq,k,ci] */
+                           const float* kernel_points, int32_t k,
+                           const float* deformed_kp, const float* modulations,
+                           float extent, int32_t influence, int32_t aggregation,
+                           float* dx,                 /* out [ns,ci] (fully overwritten) */
+                           void* stream);
+
+int ws_kpconv_gather_bwd_geom(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                              const int64_t* inds, int32_t h,
+                              const float* x, int32_t ci,
+                              const float* dwf,          /* [nq,k,ci] */
+                              const float* kernel_points, int32_t k,
+                              const float* deformed_kp,  /* [nq,k,3], required */
+                              const float* modulations,  /* [nq,k] or NULL */
+                              const float* d_min_d2,     /* [nq,k] or NULL */
+                              float extent, int32_t influence, int32_t aggregation,
+                              float* d_deformed_kp,      /* out [nq,k,3] */
+                              float* d_modulations,      /* out [nq,k] or NULL */
+                              void* stream);
+
+/* Transposed neighbour table (support -> list of flat pair ids q*h+col), the deterministic
+ * replacement of the scatter_add in the autograd of blocks.gather (blocks.py:36-67).
+ * t_offsets [ns+2] int32: entries of support s are t_pairs[t_offsets[s] .. t_offsets[s+1]);
+ * slot ns collects the shadow pairs.  Lists are sorted by pair id.  Requires nq*h < 2^31.
+ * scratch: at least ws_transpose_scratch_bytes(nq,h,ns) bytes. */
+int64_t ws_transpose_scratch_bytes(int64_t nq, int32_t h, int64_t ns);
+int ws_transpose_build(const int64_t* inds, int64_t nq, int32_t h, int64_t ns,
+                       int32_t* t_offsets, int32_t* t_pairs, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling helpers (models/blocks.py:80-111).
+ * ws_max_pool_fwd: out[q,c] = max_h xpad[inds[q,h], c] with xpad = [x; 0] (blocks.py:95-111);
+ *   arg[q,c] = the column h of the (first) maximum, kept for the backward.
+ * ws_max_pool_bwd: dx[s,c] = sum of dy[q,c] over (q,h) with inds[q,h]==s and arg[q,c]==h.
+ * ws_closest_pool_fwd: out[q,:] = xpad[inds[q,0], :] (blocks.py:80-92).
+ * ws_closest_pool_bwd: dx[s,:] = sum of dy[q,:] over q with inds[q,0]==s.
+ * The backward forms take the transposed table of `inds` (ws_transpose_build).
+ * ------------------------------------------------------------------------------------------ */
+int ws_max_pool_fwd(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                    float* out, int32_t* arg, void* stream);
+int ws_max_pool_bwd(const float* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c,
+                    const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns,
+                    float* dx, void* stream);
+int ws_closest_pool_fwd(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                        float* out, void* stream);
+int ws_closest_pool_bwd(const float* dy, int64_t nq, int32_t h, int32_t c,
+                        const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns,
+                        float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Radius neighbours -- replaces cpp_wrappers/cpp_neighbors (radius_neighbors.batch_query,
+ * wrapper.cpp:58-238 -> batch_nanoflann_neighbors, neighbors/neighbors.cpp:211-332).
+ * For every query of batch element b: supports j of the same element with
+ *   fl(fl(fl(dx*dx)+fl(dy*dy))+fl(dz*dz)) < fl(radius*radius)     (no FMA contraction)
+ * sorted ascending by that d2 (ties: by index), as global support indices; rows padded with ns.
+ *
+ * Two-call protocol (the width is data dependent, neighbors.cpp:296-304):
+ *   ws_radius_neighbors_plan   builds the per-element cell grid in `ws` and counts; synchronises
+ *                              `stream` and returns *h_max_count (host).  WS_ERR_EMPTY if it is 0
+ *                              or nq == 0.
+ *   ws_radius_neighbors_fill   writes out[nq, width] with width <= max_count columns (cropping
+ *                              columns is what datasets/common.py:336-346 does afterwards);
+ *                              exactly one of out_i32 / out_i64 is non-NULL (int64 is what
+ *                              common.py:551-553 converts to).
+ * q_lens / s_lens are DEVICE int32 [nb]; h_q_lens / h_s_lens the same values on the host.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ws_neighbors_ws ws_neighbors_ws;     /* opaque workspace, owns device scratch */
+int ws_neighbors_ws_create(ws_neighbors_ws** ws);
+void ws_neighbors_ws_destroy(ws_neighbors_ws* ws);
+int ws_radius_neighbors_plan(ws_neighbors_ws* ws,
+                             const float* queries, int64_t nq, const float* supports, int64_t ns,
+                             const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                             float radius, int32_t* h_max_count, void* stream);
+int ws_radius_neighbors_fill(ws_neighbors_ws* ws, int32_t width,
+                             int32_t* out_i32, int64_t* out_i64, void* stream);
+/* per-query neighbour counts of the last plan (device int32 [nq]); valid until the next plan.
+ * Feeds the neighbourhood-limit calibration (datasets/DALES_PseudoLabel.py:1238-1240). */
+const int32_t* ws_radius_neighbors_counts(const ws_neighbors_ws* ws);
+
+/* ------------------------------------------------------------------------------------------
+ * Grid subsampling -- replaces cpp_wrappers/cpp_subsampling (grid_subsampling.subsample_batch /
+ * subsample, wrapper.cpp:62-333,338-566 -> grid_subsampling.cpp:5-106,109-211).
+ * Per batch element: origin = floor(min*(1/dl))*dl, cell key = iX + nX*iY + nX*nY*iZ (all f32,
+ * IEEE divide), per cell the SEQUENTIAL f32 sum of its points in input order times
+ * (float)(1.0/count); features: sequential sum / (float)count; labels: arg-max of the per-cell
+ * histogram (first-seen label wins ties -- the reference's tie order is implementation-defined).
+ * order_mode WS_ORDER_REFERENCE reproduces the reference's row order (the iteration order of a
+ * libstdc++ unordered_map filled in first-occurrence order); WS_ORDER_FIRST_SEEN orders cells by
+ * first occurrence (cheaper; same set of rows).
+ *
+ * Two-call protocol:
+ *   ws_grid_subsample_plan  bins the points, synchronises and returns the per-element row counts
+ *                           h_out_lens[nb] (after max_p truncation) and *h_m = their sum.
+ *   ws_grid_subsample_fill  writes out_points [m,3] (+ out_features [m,fd], out_labels [m,ld]).
+ * ------------------------------------------------------------------------------------------ */
+enum { WS_ORDER_REFERENCE = 0, WS_ORDER_FIRST_SEEN = 1 };
+typedef struct ws_subsample_ws ws_subsample_ws;
+int ws_subsample_ws_create(ws_subsample_ws** ws);
+void ws_subsample_ws_destroy(ws_subsample_ws* ws);
+int ws_grid_subsample_plan(ws_subsample_ws* ws, const float* points, int64_t n,
+                           const int32_t* h_lens, int32_t nb, float dl, int32_t max_p,
+                           int32_t order_mode, int32_t* h_out_lens, int64_t* h_m, void* stream);
+int ws_grid_subsample_fill(ws_subsample_ws* ws,
+                           const float* features, int32_t fd,   /* [n,fd] or NULL */
+                           const int32_t* labels, int32_t ld,   /* [n,ld] or NULL */
+                           float* out_points, float* out_features, int32_t* out_labels,
+                           uint64_t* out_keys,                  /* [m] cell keys or NULL (test aid) */
+                           int32_t* out_counts,                 /* [m] points per cell or NULL */
+                           void* stream);
+
+/* Rotation of stacked clouds by one 3x3 matrix per batch element, f32, no FMA:
+ * out[i,j] = (p0*R[b,0,j] + p1*R[b,1,j]) + p2*R[b,2,j]   (transpose=1 uses R[b,j,:]),
+ * the arithmetic of datasets/common.py:116-119 and :131-135 (random grid orientation). */
+int ws_rotate_clouds(const float* points, int64_t n, const int32_t* lens /*device [nb]*/, int32_t nb,
+                     const float* rot /*device [nb,3,3]*/, int32_t transpose, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WEASAL_HIP_H */

@@ -370,7 +370,7 @@ def make_kernel_points():
     from kernels.kernel_points import load_kernels
     np.random.seed(5)
     k1 = load_kernels(0.6, 15, 3, 'center')
-    save("g9_load_kernels.npz", seed=np.int64(5), radius=np.float32(0.6), kernel_points=k1)
+    save("g9_load_kernels.npz", seed=np.int64(5), radius=np.float64(0.6), kernel_points=k1)
 
 
 if __name__ == "__main__":

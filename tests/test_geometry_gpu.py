@@ -1,0 +1,149 @@
+"""GPU parity: radius neighbours and grid subsampling (HIP, through the C ABI) against the golden
+vectors of the reference and against the CPU oracle on seeded inputs.  Integer outputs and
+barycentres are compared bit-exact (ties in d2: see conftest.assert_neighbors_equal)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_neighbors_equal, golden, sphere
+from oracle import geom
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def test_neighbors_vs_golden(gpu):
+    from weasal_amd import ops
+    g = golden("g1_neighbors.npz")
+    p, l, sp, sl = g["points"], g["lens"], g["sub_points"], g["sub_lens"]
+    P, SP = dev(p, gpu), dev(sp, gpu)
+    for r in (0.6, 1.0):
+        got = ops.radius_neighbors(P, P, l, l, r, dtype=torch.int32).cpu().numpy()
+        assert_neighbors_equal(p, p, got, g["self_r%.1f" % r], bool(g["tiefree_self_r%.1f" % r]))
+        got = ops.radius_neighbors(SP, P, sl, l, r, dtype=torch.int32).cpu().numpy()
+        assert_neighbors_equal(sp, p, got, g["pool_r%.1f" % r], bool(g["tiefree_pool_r%.1f" % r]))
+        got = ops.radius_neighbors(P, SP, l, sl, 2 * r, dtype=torch.int64).cpu().numpy()
+        assert_neighbors_equal(p, sp, got, g["up_r%.1f" % (2 * r)], bool(g["tiefree_up_r%.1f" % (2 * r)]))
+
+
+def test_neighbors_vs_oracle_random(gpu):
+    from weasal_amd import ops
+    rng = np.random.default_rng(11)
+    p = np.concatenate([sphere(rng, 6000, 4.0), sphere(rng, 1, 4.0), sphere(rng, 5000, 4.0, (3.0, 0.5, 0.1))])
+    l = np.array([6000, 1, 5000], np.int32)
+    P = dev(p, gpu)
+    for r in (0.37, 0.6, 1.2):
+        want = geom.batch_query(p, p, l, l, r)
+        got, counts = ops.radius_neighbors(P, P, l, l, r, dtype=torch.int32, return_counts=True)
+        # ties broken by index on both sides -> bit exact
+        assert np.array_equal(got.cpu().numpy(), want)
+        assert np.array_equal(counts.cpu().numpy(), (want < p.shape[0]).sum(1))
+        # cropped int64 form = leading columns
+        lim = max(1, want.shape[1] // 2)
+        got64 = ops.radius_neighbors(P, P, l, l, r, limit=lim, dtype=torch.int64).cpu().numpy()
+        assert got64.dtype == np.int64 and np.array_equal(got64, want[:, :lim])
+
+
+def test_neighbors_queries_outside_supports(gpu):
+    from weasal_amd import ops
+    rng = np.random.default_rng(12)
+    s = sphere(rng, 3000, 2.0)
+    q = np.concatenate([sphere(rng, 500, 3.5), np.array([[50, 50, 50], [-40, 0, 0]], np.float32)])
+    want = geom.batch_query(q, s, [502], [3000], 0.8)
+    got = ops.radius_neighbors(dev(q, gpu), dev(s, gpu), [502], [3000], 0.8, dtype=torch.int32).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_neighbors_empty_raises(gpu):
+    from weasal_amd import ops
+    p = dev(np.array([[0, 0, 0], [10, 10, 10]], np.float32), gpu)
+    q = dev(np.array([[5, 5, 5]], np.float32), gpu)
+    with pytest.raises(RuntimeError):
+        ops.radius_neighbors(q, p, [1], [2], 0.5)
+    with pytest.raises(RuntimeError):
+        ops.radius_neighbors(p[:0], p, [0], [2], 0.5)
+
+
+def test_subsample_vs_golden(gpu):
+    from weasal_amd import ops
+    g = golden("g2_subsample.npz")
+    P = dev(g["points"], gpu)
+    for dl in (0.3, 0.5, 0.9):
+        p, l = ops.grid_subsample(P, g["lens"], dl)
+        assert np.array_equal(l, g["l_dl%.1f" % dl])
+        assert np.array_equal(p.cpu().numpy(), g["p_dl%.1f" % dl])
+    p, l = ops.grid_subsample(P, g["lens"], 0.3, max_p=50)
+    assert np.array_equal(l, g["l_dl0.3_maxp50"]) and np.array_equal(p.cpu().numpy(), g["p_dl0.3_maxp50"])
+    p, l = ops.grid_subsample(dev(g["points2"], gpu), g["lens2"], 1.7)
+    assert np.array_equal(l, g["l2_dl1.7"]) and np.array_equal(p.cpu().numpy(), g["p2_dl1.7"])
+
+
+def test_subsample_features_labels_vs_golden(gpu):
+    from weasal_amd import ops
+    g = golden("g3_subsample_fl.npz")
+    p, l, f, c = ops.grid_subsample(dev(g["points"], gpu), g["lens"], 0.5, features=dev(g["features"], gpu),
+                                    labels=dev(g["labels"], gpu))
+    assert np.array_equal(l, g["b_lens"]) and np.array_equal(p.cpu().numpy(), g["b_points"])
+    assert np.array_equal(f.cpu().numpy(), g["b_features"])
+    assert np.array_equal(c.cpu().numpy(), g["b_labels"])
+
+
+@pytest.mark.parametrize("n,R,dl", [(20000, 6.0, 0.48), (50000, 10.0, 0.8), (50000, 10.0, 3.2)])
+def test_subsample_vs_oracle_random(gpu, n, R, dl):
+    """row order (libstdc++ unordered_map iteration order), keys, counts, barycentres: bit exact"""
+    from weasal_amd import ops
+    rng = np.random.default_rng(n)
+    p = np.concatenate([sphere(rng, n, R), sphere(rng, n // 2, R, (1.0, -2.0, 0.3))])
+    l = np.array([n, n // 2], np.int32)
+    wp, wl, wk, wc = geom.subsample_batch(p, l, sampleDl=dl, with_keys=True)
+    gp, gl, gk, gc = ops.grid_subsample(dev(p, gpu), l, dl, return_keys=True)
+    assert np.array_equal(gl, wl)
+    assert np.array_equal(gk.cpu().numpy().view(np.uint64), wk)
+    assert np.array_equal(gc.cpu().numpy(), wc)
+    assert np.array_equal(gp.cpu().numpy(), wp)
+    # first-seen order: same rows as a set
+    fp, fl = ops.grid_subsample(dev(p, gpu), l, dl, reference_order=False)
+    assert np.array_equal(fl, wl)
+    a = fp.cpu().numpy()
+    i0 = 0
+    for n_b in wl:
+        ga = a[i0:i0 + n_b]
+        wa = wp[i0:i0 + n_b]
+        assert np.array_equal(ga[np.lexsort(ga.T)], wa[np.lexsort(wa.T)])
+        i0 += n_b
+
+
+def test_rotate_clouds(gpu):
+    from weasal_amd import ops
+    rng = np.random.default_rng(2)
+    p = rng.normal(size=(1000, 3)).astype(np.float32)
+    lens = np.array([300, 700], np.int32)
+    R = rng.normal(size=(2, 3, 3)).astype(np.float32)
+    want = p.copy()
+    want[:300] = np.sum(np.expand_dims(p[:300], 2) * R[0], axis=1)          # datasets/common.py:118
+    want[300:] = np.sum(np.expand_dims(p[300:], 2) * R[1], axis=1)
+    got = ops.rotate_clouds(dev(p, gpu), dev(lens, gpu), dev(R, gpu)).cpu().numpy()
+    assert np.array_equal(got, want)
+    want_t = p.copy()
+    want_t[:300] = np.sum(np.expand_dims(p[:300], 2) * R[0].T, axis=1)      # datasets/common.py:133
+    want_t[300:] = np.sum(np.expand_dims(p[300:], 2) * R[1].T, axis=1)
+    got = ops.rotate_clouds(dev(p, gpu), dev(lens, gpu), dev(R, gpu), transpose=True).cpu().numpy()
+    assert np.array_equal(got, want_t)
+
+
+def test_full_size_dales_batch(gpu):
+    """BASELINE config 3 sizes (8 spheres x 50k, r = 1 m, dl = 0.8): GPU rows equal the oracle's."""
+    from weasal_amd import ops
+    rng = np.random.default_rng(77)
+    p = np.concatenate([sphere(rng, 50000, 10.0) for _ in range(8)])
+    l = np.full(8, 50000, np.int32)
+    P = dev(p, gpu)
+    want = geom.batch_query(p, p, l, l, 1.0)
+    got = ops.radius_neighbors(P, P, l, l, 1.0, dtype=torch.int32).cpu().numpy()
+    assert np.array_equal(got, want)
+    wp, wl = geom.subsample_batch(p, l, sampleDl=0.8)
+    gp, gl = ops.grid_subsample(P, l, 0.8)
+    assert np.array_equal(gl, wl) and np.array_equal(gp.cpu().numpy(), wp)

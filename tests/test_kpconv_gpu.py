@@ -1,0 +1,149 @@
+"""GPU parity: fused KPConv kernels (through the C ABI) against the golden vectors generated from
+the reference's models/blocks.py.  Tolerance (BASELINE.json north_star): 1e-4 relative on fp32
+activations, taken as max|a-b| <= 1e-4 * max|ref| per tensor (summation order differs from
+torch's bmm); gradients use the same bound."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def build_conv(g, device, ci, co, **kw):
+    from weasal_amd.blocks import KPConv
+    np.random.seed(0)
+    conv = KPConv(15, 3, ci, co, float(g["KP_extent"]), float(g["radius"]), **kw)
+    with torch.no_grad():
+        conv.weights.copy_(torch.from_numpy(g["weights"]))
+        conv.kernel_points.copy_(torch.from_numpy(g["kernel_points"]))
+        if kw.get("deformable"):
+            conv.offset_conv.weights.copy_(torch.from_numpy(g["offset_weights"]))
+            conv.offset_conv.kernel_points.copy_(torch.from_numpy(g["offset_kernel_points"]))
+            conv.offset_bias.copy_(torch.from_numpy(g["offset_bias"]))
+    return conv.to(device)
+
+
+RIGID = [("g4_kpconv_3_64.npz", {}), ("g4_kpconv_32_32.npz", {}), ("g4_kpconv_32_32_strided.npz", {}),
+         ("g4_kpconv_64_64.npz", {}), ("g4_kpconv_16_16_gaussian.npz", {"KP_influence": "gaussian"}),
+         ("g4_kpconv_16_16_constant.npz", {"KP_influence": "constant"}),
+         ("g4_kpconv_16_16_closest.npz", {"aggregation_mode": "closest"})]
+
+
+@pytest.mark.parametrize("name,kw", RIGID)
+def test_rigid_kpconv_forward_backward(gpu, name, kw):
+    g = golden(name)
+    ci, co = g["x"].shape[1], g["out"].shape[1]
+    conv = build_conv(g, gpu, ci, co, **kw)
+    x = torch.from_numpy(g["x"]).to(gpu).requires_grad_(True)
+    out = conv(torch.from_numpy(g["q_pts"]).to(gpu), torch.from_numpy(g["s_pts"]).to(gpu),
+               torch.from_numpy(g["inds"]).to(gpu), x)
+    assert rel(out.detach().cpu().numpy(), g["out"]) < TOL
+    (out * torch.from_numpy(g["dy"]).to(gpu)).sum().backward()
+    assert rel(x.grad.cpu().numpy(), g["grad_x"]) < TOL
+    assert rel(conv.weights.grad.cpu().numpy(), g["grad_weights"]) < TOL
+    assert conv.kernel_points.grad is None
+
+
+DEFORM = [("g5_kpconv_deform_16_16.npz", False), ("g5_kpconv_deform_mod_16_32.npz", True),
+          ("g5_kpconv_deform_strided_16_16.npz", False)]
+
+
+@pytest.mark.parametrize("name,modulated", DEFORM)
+def test_deformable_kpconv(gpu, name, modulated):
+    import types
+    from weasal_amd.architectures import p2p_fitting_regularizer
+    g = golden(name)
+    ci, co = g["x"].shape[1], g["out"].shape[1]
+    conv = build_conv(g, gpu, ci, co, deformable=True, modulated=modulated)
+    x = torch.from_numpy(g["x"]).to(gpu).requires_grad_(True)
+    out = conv(torch.from_numpy(g["q_pts"]).to(gpu), torch.from_numpy(g["s_pts"]).to(gpu),
+               torch.from_numpy(g["inds"]).to(gpu), x)
+    assert rel(conv.offset_features.detach().cpu().numpy(), g["offset_features"]) < TOL
+    assert rel(conv.deformed_KP.detach().cpu().numpy(), g["deformed_KP"]) < TOL
+    assert rel(conv.min_d2.detach().cpu().numpy(), g["min_d2"]) < TOL
+    assert rel(out.detach().cpu().numpy(), g["out"]) < TOL
+    net = types.SimpleNamespace(modules=lambda: [conv], l1=torch.nn.L1Loss(), K=15, repulse_extent=1.2,
+                                deform_fitting_power=1.0)
+    reg = p2p_fitting_regularizer(net)
+    assert abs(float(reg) - float(g["reg_loss"])) <= TOL * abs(float(g["reg_loss"]))
+    ((out * torch.from_numpy(g["dy"]).to(gpu)).sum() + reg).backward()
+    # offset gradients chain two KPConvs and a sqrt: 5e-4 of the tensor's max
+    assert rel(x.grad.cpu().numpy(), g["grad_x"]) < 5 * TOL
+    assert rel(conv.weights.grad.cpu().numpy(), g["grad_weights"]) < TOL
+    assert rel(conv.offset_conv.weights.grad.cpu().numpy(), g["grad_offset_weights"]) < 5 * TOL
+    assert rel(conv.offset_bias.grad.cpu().numpy(), g["grad_offset_bias"]) < 5 * TOL
+
+
+def test_pools(gpu):
+    from weasal_amd import blocks
+    g = golden("g6_pools.npz")
+    x = torch.from_numpy(g["x"]).to(gpu).requires_grad_(True)
+    mp = blocks.max_pool(x, torch.from_numpy(g["inds"]).to(gpu))
+    assert np.array_equal(mp.detach().cpu().numpy(), g["max_pool"])
+    (mp * torch.from_numpy(g["dy"]).to(gpu)).sum().backward()
+    assert rel(x.grad.cpu().numpy(), g["grad_max_pool"]) < 1e-6
+    xc = torch.from_numpy(g["xc"]).to(gpu).requires_grad_(True)
+    cp = blocks.closest_pool(xc, torch.from_numpy(g["up"]).to(gpu))
+    assert np.array_equal(cp.detach().cpu().numpy(), g["closest_pool"])
+    (cp * torch.from_numpy(g["dyc"]).to(gpu)).sum().backward()
+    assert rel(xc.grad.cpu().numpy(), g["grad_closest_pool"]) < 1e-6
+    ga = blocks.global_average(x.detach(), g["lengths"])
+    assert rel(ga.cpu().numpy(), g["global_average"]) < 1e-6
+
+
+def test_cpu_tensors_are_rejected():
+    """no CPU fallback: the operators refuse host tensors loudly"""
+    from weasal_amd import _lib, ops
+    x = torch.zeros(4, 8)
+    with pytest.raises(_lib.WeasalHipError):
+        ops.max_pool(x, torch.zeros(4, 2, dtype=torch.int64))
+
+
+def test_transposed_table_matches_scatter(gpu):
+    from weasal_amd import ops
+    rng = np.random.default_rng(0)
+    ns, nq, h = 1000, 700, 37
+    inds = torch.from_numpy(rng.integers(0, ns + 1, size=(nq, h))).to(gpu)
+    t = ops.TransposedTable(inds, ns)
+    off = t.offsets.cpu().numpy()
+    pairs = t.pairs.cpu().numpy()
+    flat = inds.cpu().numpy().reshape(-1)
+    assert off[0] == 0 and off[ns + 1] == nq * h
+    for s in list(range(0, ns + 1, 97)) + [ns]:
+        want = np.nonzero(flat == s)[0]
+        assert np.array_equal(pairs[off[s]:off[s + 1]], want)
+
+
+def test_large_kpconv_properties(gpu):
+    """DALES-sized layer (BASELINE config 3, enc1: N=400k would need the pyramid; here 60k x 59,
+    32->32): linearity in x and agreement of the backward with a finite-difference direction."""
+    from weasal_amd import ops
+    rng = np.random.default_rng(5)
+    n, h, ci = 60000, 59, 32
+    pts = torch.from_numpy(rng.uniform(-10, 10, size=(n, 3)).astype(np.float32)).to(gpu)
+    inds = torch.from_numpy(rng.integers(0, n + 1, size=(n, h))).to(gpu)
+    # make neighbours geometrically close: q + small offset points
+    s_pts = pts
+    kp = torch.from_numpy(rng.normal(scale=0.4, size=(15, 3)).astype(np.float32)).to(gpu)
+    x1 = torch.randn(n, ci, device=gpu)
+    x2 = torch.randn(n, ci, device=gpu)
+    f = lambda x: ops.kpconv_gather(x, pts, s_pts, inds, kp, 20.0)[0]
+    a, b, c = f(x1), f(x2), f(x1 + 2 * x2)
+    assert torch.allclose(c, a + 2 * b, rtol=1e-4, atol=1e-3)
+    xg = x1.clone().requires_grad_(True)
+    wf = ops.kpconv_gather(xg, pts, s_pts, inds, kp, 20.0)[0]
+    dy = torch.randn_like(wf)
+    (wf * dy).sum().backward()
+    # <dy, f(x2)> == <grad, x2> by linearity
+    lhs = (dy * b).sum().item()
+    rhs = (xg.grad * x2).sum().item()
+    assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), 1.0)

@@ -1,0 +1,88 @@
+"""ctypes binding of libweasal_hip.so (the C ABI declared in include/weasal_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C weasal_amd/csrc``.
+There is NO fallback: if the shared object is missing or a symbol cannot be resolved the
+import of any compute path raises, so that a silent CPU/PyTorch substitute can never stand
+in for the HIP kernels.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libweasal_hip.so")
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+
+# name -> (restype, argtypes); mirrors include/weasal_hip.h declaration by declaration
+SIGNATURES = {
+    "ws_last_error": (C.c_char_p, []),
+    "ws_version": (C.c_char_p, []),
+    "ws_device_count": (C.c_int, []),
+    "ws_kpconv_gather_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp,
+                                      _f32, _i32, _i32, _vp, _vp, _vp]),
+    "ws_kpconv_gather_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32,
+                                        _vp, _vp, _f32, _i32, _i32, _vp, _vp]),
+    "ws_kpconv_gather_bwd_geom": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _i32,
+                                           _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp]),
+    "ws_transpose_scratch_bytes": (_i64, [_i64, _i32, _i64]),
+    "ws_transpose_build": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "ws_max_pool_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "ws_max_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "ws_closest_pool_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
+    "ws_closest_pool_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "ws_neighbors_ws_create": (C.c_int, [C.POINTER(_vp)]),
+    "ws_neighbors_ws_destroy": (None, [_vp]),
+    "ws_radius_neighbors_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32,
+                                          C.POINTER(_i32), _vp]),
+    "ws_radius_neighbors_fill": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
+    "ws_radius_neighbors_counts": (_vp, [_vp]),
+    "ws_subsample_ws_create": (C.c_int, [C.POINTER(_vp)]),
+    "ws_subsample_ws_destroy": (None, [_vp]),
+    "ws_grid_subsample_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _f32, _i32, _i32, _vp,
+                                        C.POINTER(_i64), _vp]),
+    "ws_grid_subsample_fill": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws_rotate_clouds": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class WeasalHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WeasalHipError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C weasal_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Map a ws_status to the exception type the reference's modules raise (RuntimeError)."""
+    if rc != 0:
+        msg = lib().ws_last_error()
+        raise WeasalHipError("libweasal_hip status %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """device/host pointer of a tensor (None -> NULL)"""
+    return None if t is None else _vp(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return _vp(torch.cuda.current_stream().cuda_stream)

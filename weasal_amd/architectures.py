@@ -1,0 +1,145 @@
+"""KP-FCNN segmentation network with the API of the reference's models/architectures.py.
+
+``KPFCNN(config, lbl_values, ign_lbls)``, ``.forward(batch, config)``, ``.loss``, ``.accuracy``
+keep the reference's names, wiring and state_dict keys (models/architectures.py:192-403), so
+``utils/trainer_PseudoLabel.py`` drives this class unchanged; every KPConv / pooling operator
+underneath is a HIP kernel (weasal_amd/blocks.py).  ``p2p_fitting_regularizer`` follows
+architectures.py:24-57.  Not provided here: ``contrast_loss`` (architectures.py:405-504, needs
+torch_scatter) and the weak-label ``KPFCNN_mprm`` (rank 3).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .blocks import KPConv, UnaryBlock, block_decider
+
+_LAYER_CHANGE = ('pool', 'strided', 'upsample', 'global')
+
+
+def p2p_fitting_regularizer(net):
+    """Deformable-KPConv regulariser: 2 * L1(min_d2 / extent^2) fitting term plus the pairwise
+    repulsion of the deformed kernel points closer than `repulse_extent` (architectures.py:24-57)."""
+    fitting_loss = 0
+    repulsive_loss = 0
+    for m in net.modules():
+        if not (isinstance(m, KPConv) and m.deformable):
+            continue
+        kp_min_d2 = m.min_d2 / (m.KP_extent ** 2)
+        fitting_loss = fitting_loss + net.l1(kp_min_d2, torch.zeros_like(kp_min_d2))
+        locs = m.deformed_KP / m.KP_extent                                   # [N, K, 3]
+        for i in range(net.K):
+            others = torch.cat([locs[:, :i, :], locs[:, i + 1:, :]], dim=1).detach()
+            dist = torch.sqrt(torch.sum((others - locs[:, i:i + 1, :]) ** 2, dim=2))
+            rep = torch.sum(torch.clamp_max(dist - net.repulse_extent, max=0.0) ** 2, dim=1)
+            repulsive_loss = repulsive_loss + net.l1(rep, torch.zeros_like(rep)) / net.K
+    return net.deform_fitting_power * (2 * fitting_loss + repulsive_loss)
+
+
+class KPFCNN(nn.Module):
+    """Encoder / decoder KP-FCNN built from config.architecture (architectures.py:197-326)."""
+
+    def __init__(self, config, lbl_values, ign_lbls):
+        super(KPFCNN, self).__init__()
+        arch = list(config.architecture)
+        layer = 0
+        r = config.first_subsampling_dl * config.conv_radius
+        in_dim = config.in_features_dim
+        out_dim = config.first_features_dim
+        self.K = config.num_kernel_points
+        self.C = len(lbl_values) - len(ign_lbls)
+
+        # ---- encoder: every block up to the first upsampling
+        self.encoder_blocks = nn.ModuleList()
+        self.encoder_skip_dims = []
+        self.encoder_skips = []
+        for block_i, block in enumerate(arch):
+            if 'equivariant' in block and out_dim % 3 != 0:
+                raise ValueError('Equivariant block but features dimension is not a factor of 3')
+            if any(tag in block for tag in _LAYER_CHANGE):
+                self.encoder_skips.append(block_i)
+                self.encoder_skip_dims.append(in_dim)
+            if 'upsample' in block:
+                break
+            self.encoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim // 2 if 'simple' in block else out_dim
+            if 'pool' in block or 'strided' in block:
+                layer += 1
+                r *= 2
+                out_dim *= 2
+
+        # ---- decoder: from the first upsampling on, skip features concatenated after each upsampling
+        self.decoder_blocks = nn.ModuleList()
+        self.decoder_concats = []
+        start_i = next((i for i, b in enumerate(arch) if 'upsample' in b), 0)
+        for block_i, block in enumerate(arch[start_i:]):
+            if block_i > 0 and 'upsample' in arch[start_i + block_i - 1]:
+                in_dim += self.encoder_skip_dims[layer]
+                self.decoder_concats.append(block_i)
+            self.decoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim
+            if 'upsample' in block:
+                layer -= 1
+                r *= 0.5
+                out_dim = out_dim // 2
+
+        # heads: Linear + bias + LeakyReLU, on the logits too (architectures.py:299-300)
+        self.head_mlp = UnaryBlock(out_dim, config.first_features_dim, False, 0)
+        self.head_softmax = UnaryBlock(config.first_features_dim, self.C, False, 0)
+        self.dropout = config.dropout
+        if config.dropout:
+            self.droplayer = nn.Dropout(p=float(config.dropout))
+
+        # ---- losses
+        self.valid_labels = np.sort([c for c in lbl_values if c not in ign_lbls])
+        if len(config.class_w) > 0:
+            class_w = torch.from_numpy(np.array(config.class_w, dtype=np.float32))
+            self.criterion = torch.nn.CrossEntropyLoss(weight=class_w, ignore_index=-1)
+        else:
+            self.criterion = torch.nn.CrossEntropyLoss(ignore_index=-1)
+        self.deform_fitting_mode = config.deform_fitting_mode
+        self.deform_fitting_power = config.deform_fitting_power
+        self.deform_lr_factor = config.deform_lr_factor
+        self.repulse_extent = config.repulse_extent
+        self.output_loss = 0
+        self.reg_loss = 0
+        self.l1 = nn.L1Loss()
+
+    def forward(self, batch, config):
+        x = batch.features.clone().detach()
+        skips = []
+        for block_i, block_op in enumerate(self.encoder_blocks):
+            if block_i in self.encoder_skips:
+                skips.append(x)
+            x = block_op(x, batch)
+        for block_i, block_op in enumerate(self.decoder_blocks):
+            if block_i in self.decoder_concats:
+                x = torch.cat([x, skips.pop()], dim=1)
+            x = block_op(x, batch)
+        if self.dropout:
+            x = self.droplayer(x)
+        x = self.head_mlp(x, batch)
+        return self.head_softmax(x, batch)
+
+    def _targets(self, labels):
+        """labels -> class index in [0, C) or -1 for ignored labels (architectures.py:362-365)"""
+        target = -torch.ones_like(labels)
+        for i, c in enumerate(self.valid_labels):
+            target[labels == c] = i
+        return target
+
+    def loss(self, outputs, labels):
+        """cross entropy over [1, C, N] with ignore_index -1, plus the deformable regulariser"""
+        target = self._targets(labels)
+        self.output_loss = self.criterion(outputs.transpose(0, 1).unsqueeze(0), target.unsqueeze(0))
+        if self.deform_fitting_mode == 'point2point':
+            self.reg_loss = p2p_fitting_regularizer(self)
+        elif self.deform_fitting_mode == 'point2plane':
+            raise ValueError('point2plane fitting mode not implemented yet.')
+        else:
+            raise ValueError('Unknown fitting mode: ' + self.deform_fitting_mode)
+        return self.output_loss + self.reg_loss
+
+    def accuracy(self, outputs, labels):
+        target = self._targets(labels)
+        predicted = torch.argmax(outputs.data, dim=1)
+        return (predicted == target).sum().item() / target.size(0)

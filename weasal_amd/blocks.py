@@ -1,0 +1,345 @@
+"""Network blocks with the module API of the reference's models/blocks.py, on HIP kernels.
+
+Same class names, constructor arguments, attribute names, parameter / state_dict keys and
+``forward`` signatures as the reference (models/blocks.py:36-755), so that
+``models.architectures`` / ``utils.trainer_*`` code and reference checkpoints work unchanged.
+What differs is the implementation: ``KPConv.forward`` never materialises the
+[N,H,3] / [N,H,K,3] / [N,H,K] / [N,H,Ci] tensors of blocks.py:278-363 -- the gather, the
+kernel-point influence and the feature aggregate run fused in one HIP kernel
+(weasal_amd/csrc/kpconv.hip); the remaining dense contraction [N, K*Ci] x [K*Ci, Co] and the unary
+MLPs are plain GEMMs (rocBLAS/hipBLASLt through torch, i.e. MFMA).
+
+Quirks of the reference that are preserved on purpose:
+  * BatchNormBlock is an identity for 2-D inputs when use_bn is set (blocks.py:454-463); the
+    BatchNorm1d parameters exist in the state_dict but never run;
+  * shadow neighbours (index == number of supports) are the point (1e6,1e6,1e6) with a zero
+    feature row (blocks.py:278,357); max_pool includes that zero row (blocks.py:104).
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.init import kaiming_uniform_
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .kernel_points import load_kernels
+
+
+# ---------------------------------------------------------------------------------------------
+# free functions (blocks.py:36-134)
+# ---------------------------------------------------------------------------------------------
+def gather(x, idx, method=2):
+    """x[idx] for idx of any shape (blocks.py:36-67; the three `method`s there only differ in how
+    autograd scatters the gradient back -- all are x[idx])."""
+    if method not in (0, 1, 2):
+        raise ValueError('Unkown method')
+    return x[idx]
+
+
+def radius_gaussian(sq_r, sig, eps=1e-9):
+    """exp(-sq_r / (2 sig^2 + eps))  (blocks.py:70-77)"""
+    return torch.exp(-sq_r / (2 * sig ** 2 + eps))
+
+
+def closest_pool(x, inds):
+    """features of the closest (first-column) neighbour, zero row for shadow (blocks.py:80-92)"""
+    return ops.closest_pool(x, inds)
+
+
+def max_pool(x, inds):
+    """max over the neighbourhood, the zero shadow row takes part (blocks.py:95-111)"""
+    return ops.max_pool(x, inds)
+
+
+def global_average(x, batch_lengths):
+    """per-cloud mean of the stacked features (blocks.py:114-134)"""
+    lengths = [int(v) for v in batch_lengths]
+    return torch.stack([chunk.mean(dim=0) for chunk in torch.split(x, lengths, dim=0)])
+
+
+# ---------------------------------------------------------------------------------------------
+# KPConv (blocks.py:144-379)
+# ---------------------------------------------------------------------------------------------
+class KPConv(nn.Module):
+
+    def __init__(self, kernel_size, p_dim, in_channels, out_channels, KP_extent, radius,
+                 fixed_kernel_points='center', KP_influence='linear', aggregation_mode='sum',
+                 deformable=False, modulated=False):
+        super(KPConv, self).__init__()
+        self.K = kernel_size
+        self.p_dim = p_dim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.radius = radius
+        self.KP_extent = KP_extent
+        self.fixed_kernel_points = fixed_kernel_points
+        self.KP_influence = KP_influence
+        self.aggregation_mode = aggregation_mode
+        self.deformable = deformable
+        self.modulated = modulated
+
+        # read by architectures.p2p_fitting_regularizer (architectures.py:31-48)
+        self.min_d2 = None
+        self.deformed_KP = None
+        self.offset_features = None
+
+        self.weights = Parameter(torch.zeros((self.K, in_channels, out_channels), dtype=torch.float32),
+                                 requires_grad=True)
+        if deformable:
+            self.offset_dim = (self.p_dim + 1) * self.K if modulated else self.p_dim * self.K
+            self.offset_conv = KPConv(self.K, self.p_dim, self.in_channels, self.offset_dim, KP_extent, radius,
+                                      fixed_kernel_points=fixed_kernel_points, KP_influence=KP_influence,
+                                      aggregation_mode=aggregation_mode)
+            self.offset_bias = Parameter(torch.zeros(self.offset_dim, dtype=torch.float32), requires_grad=True)
+        else:
+            self.offset_dim = None
+            self.offset_conv = None
+            self.offset_bias = None
+
+        self.reset_parameters()
+        self.kernel_points = self.init_KP()
+
+    def reset_parameters(self):
+        kaiming_uniform_(self.weights, a=math.sqrt(5))
+        if self.deformable:
+            nn.init.zeros_(self.offset_bias)
+
+    def init_KP(self):
+        """frozen kernel-point parameter (blocks.py:223-236)"""
+        k_points = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
+        return Parameter(torch.tensor(k_points, dtype=torch.float32), requires_grad=False)
+
+    def forward(self, q_pts, s_pts, neighb_inds, x):
+        if self.KP_influence not in ops.INFLUENCE:
+            raise ValueError('Unknown influence function type (config.KP_influence)')
+        if self.aggregation_mode not in ops.AGGREGATION:
+            raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
+
+        deformed = None
+        modulations = None
+        if self.deformable:
+            # offsets from a rigid KPConv on the same neighbourhood (blocks.py:244-267)
+            self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x) + self.offset_bias
+            nkp = self.p_dim * self.K
+            if self.modulated:
+                unscaled = self.offset_features[:, :nkp].reshape(-1, self.K, self.p_dim)
+                modulations = 2 * torch.sigmoid(self.offset_features[:, nkp:])
+            else:
+                unscaled = self.offset_features.reshape(-1, self.K, self.p_dim)
+            self.deformed_KP = unscaled * self.KP_extent + self.kernel_points      # blocks.py:267,288
+            deformed = self.deformed_KP
+
+        wf, min_d2 = ops.kpconv_gather(x, q_pts, s_pts, neighb_inds, self.kernel_points, self.KP_extent,
+                                       influence=self.KP_influence, aggregation=self.aggregation_mode,
+                                       deformed_kp=deformed, modulations=modulations,
+                                       want_min_d2=self.deformable)
+        if self.deformable:
+            self.min_d2 = min_d2                                                     # blocks.py:304
+        # dense contraction over (kernel point, input channel): blocks.py:370-374
+        return torch.matmul(wf.reshape(wf.shape[0], -1),
+                            self.weights.reshape(self.K * self.in_channels, self.out_channels))
+
+    def __repr__(self):
+        return 'KPConv(radius: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(self.radius, self.in_channels,
+                                                                              self.out_channels)
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks (blocks.py:387-755)
+# ---------------------------------------------------------------------------------------------
+_SIMPLE = ('simple', 'simple_deformable', 'simple_invariant', 'simple_equivariant', 'simple_strided',
+           'simple_deformable_strided', 'simple_invariant_strided', 'simple_equivariant_strided')
+_RESNETB = ('resnetb', 'resnetb_invariant', 'resnetb_equivariant', 'resnetb_deformable', 'resnetb_strided',
+            'resnetb_deformable_strided', 'resnetb_equivariant_strided', 'resnetb_invariant_strided')
+
+
+def block_decider(block_name, radius, in_dim, out_dim, layer_ind, config):
+    if block_name == 'unary':
+        return UnaryBlock(in_dim, out_dim, config.use_batch_norm, config.batch_norm_momentum)
+    if block_name in _SIMPLE:
+        return SimpleBlock(block_name, in_dim, out_dim, radius, layer_ind, config)
+    if block_name in _RESNETB:
+        return ResnetBottleneckBlock(block_name, in_dim, out_dim, radius, layer_ind, config)
+    if block_name in ('max_pool', 'max_pool_wide'):
+        return MaxPoolBlock(layer_ind)
+    if block_name == 'global_average':
+        return GlobalAverageBlock()
+    if block_name == 'nearest_upsample':
+        return NearestUpsampleBlock(layer_ind)
+    raise ValueError('Unknown block name in the architecture definition : ' + block_name)
+
+
+class BatchNormBlock(nn.Module):
+    """BatchNorm1d holder that is an identity on [N,C] inputs when use_bn (blocks.py:453-463),
+    a learned bias otherwise (:465)."""
+
+    def __init__(self, in_dim, use_bn, bn_momentum):
+        super(BatchNormBlock, self).__init__()
+        self.bn_momentum = bn_momentum
+        self.use_bn = use_bn
+        self.in_dim = in_dim
+        if self.use_bn:
+            self.batch_norm = nn.BatchNorm1d(in_dim, momentum=bn_momentum)
+        else:
+            self.bias = Parameter(torch.zeros(in_dim, dtype=torch.float32), requires_grad=True)
+
+    def reset_parameters(self):
+        nn.init.zeros_(self.bias)
+
+    def forward(self, x):
+        if not self.use_bn:
+            return x + self.bias
+        if x.dim() < 3:
+            return x
+        # 3-D inputs never occur on this path; kept for interface parity (blocks.py:458-462)
+        y = self.batch_norm(x.unsqueeze(2).transpose(0, 2))
+        return y.transpose(0, 2)
+
+    def __repr__(self):
+        return 'BatchNormBlock(in_feat: {:d}, momentum: {:.3f}, only_bias: {:s})'.format(
+            self.in_dim, self.bn_momentum, str(not self.use_bn))
+
+
+class UnaryBlock(nn.Module):
+    """Linear(no bias) -> BatchNormBlock -> LeakyReLU(0.1) unless no_relu (blocks.py:473-507)"""
+
+    def __init__(self, in_dim, out_dim, use_bn, bn_momentum, no_relu=False):
+        super(UnaryBlock, self).__init__()
+        self.bn_momentum = bn_momentum
+        self.use_bn = use_bn
+        self.no_relu = no_relu
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.mlp = nn.Linear(in_dim, out_dim, bias=False)
+        self.batch_norm = BatchNormBlock(out_dim, self.use_bn, self.bn_momentum)
+        if not no_relu:
+            self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, x, batch=None):
+        x = self.batch_norm(self.mlp(x))
+        return x if self.no_relu else self.leaky_relu(x)
+
+    def __repr__(self):
+        return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
+            self.in_dim, self.out_dim, str(self.use_bn), str(not self.no_relu))
+
+
+def _layer_geometry(block_name, layer_ind, batch):
+    """(q_pts, s_pts, neighb_inds) of a block: pooled queries for strided blocks (blocks.py:554-561)"""
+    if 'strided' in block_name:
+        return batch.points[layer_ind + 1], batch.points[layer_ind], batch.pools[layer_ind]
+    return batch.points[layer_ind], batch.points[layer_ind], batch.neighbors[layer_ind]
+
+
+def _make_kpconv(block_name, in_dim, out_dim, radius, config):
+    extent = radius * config.KP_extent / config.conv_radius                       # blocks.py:523
+    return KPConv(config.num_kernel_points, config.in_points_dim, in_dim, out_dim, extent, radius,
+                  fixed_kernel_points=config.fixed_kernel_points, KP_influence=config.KP_influence,
+                  aggregation_mode=config.aggregation_mode, deformable='deform' in block_name,
+                  modulated=config.modulated)
+
+
+class SimpleBlock(nn.Module):
+    """KPConv(in -> out//2) -> BN -> LeakyReLU (blocks.py:510-564)"""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(SimpleBlock, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.KPConv = _make_kpconv(block_name, in_dim, out_dim // 2, radius, config)
+        self.batch_norm = BatchNormBlock(out_dim // 2, self.use_bn, self.bn_momentum)
+        self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, x, batch):
+        q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
+        return self.leaky_relu(self.batch_norm(self.KPConv(q_pts, s_pts, inds, x)))
+
+
+class SimpleBlock2(nn.Module):
+    """SimpleBlock with the full out_dim (blocks.py:567-622; used by the attention blocks)"""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(SimpleBlock2, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.KPConv = _make_kpconv(block_name, in_dim, out_dim, radius, config)
+        self.batch_norm = BatchNormBlock(out_dim, self.use_bn, self.bn_momentum)
+        self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, x, batch):
+        q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
+        return self.leaky_relu(self.batch_norm(self.KPConv(q_pts, s_pts, inds, x)))
+
+
+class ResnetBottleneckBlock(nn.Module):
+    """unary(in -> out/4) -> KPConv(out/4 -> out/4) -> unary(out/4 -> out) + shortcut
+    (max-pooled when strided, projected when in != out), LeakyReLU (blocks.py:624-709)"""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(ResnetBottleneckBlock, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.block_name = block_name
+        self.layer_ind = layer_ind
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        mid = out_dim // 4
+        self.unary1 = UnaryBlock(in_dim, mid, self.use_bn, self.bn_momentum) if in_dim != mid else nn.Identity()
+        self.KPConv = _make_kpconv(block_name, mid, mid, radius, config)
+        self.batch_norm_conv = BatchNormBlock(mid, self.use_bn, self.bn_momentum)
+        self.unary2 = UnaryBlock(mid, out_dim, self.use_bn, self.bn_momentum, no_relu=True)
+        if in_dim != out_dim:
+            self.unary_shortcut = UnaryBlock(in_dim, out_dim, self.use_bn, self.bn_momentum, no_relu=True)
+        else:
+            self.unary_shortcut = nn.Identity()
+        self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, features, batch):
+        q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
+        x = self.unary1(features)
+        x = self.leaky_relu(self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x)))
+        x = self.unary2(x)
+        shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
+        return self.leaky_relu(x + self.unary_shortcut(shortcut))
+
+
+class GlobalAverageBlock(nn.Module):
+
+    def __init__(self):
+        super(GlobalAverageBlock, self).__init__()
+
+    def forward(self, x, batch):
+        return global_average(x, batch.lengths[-1])
+
+
+class NearestUpsampleBlock(nn.Module):
+
+    def __init__(self, layer_ind):
+        super(NearestUpsampleBlock, self).__init__()
+        self.layer_ind = layer_ind
+        self.name_block = 'upsample'
+
+    def forward(self, x, batch):
+        return closest_pool(x, batch.upsamples[self.layer_ind - 1])
+
+    def __repr__(self):
+        return 'NearestUpsampleBlock(layer: {:d} -> {:d})'.format(self.layer_ind, self.layer_ind - 1)
+
+
+class MaxPoolBlock(nn.Module):
+
+    def __init__(self, layer_ind):
+        super(MaxPoolBlock, self).__init__()
+        self.layer_ind = layer_ind
+
+    def forward(self, x, batch):
+        return max_pool(x, batch.pools[self.layer_ind + 1])

@@ -1,0 +1,398 @@
+// weasal_amd/csrc/neighbors.hip -- batched fixed-radius neighbour search on gfx950.
+// (compiled with -ffp-contract=off: the distance recipe must round like the reference's, no FMA)
+//
+// Replaces batch_nanoflann_neighbors (cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:211-332):
+// the kd-tree + per-query std::sort become
+//   1. per batch element: bounding box -> uniform cell grid (cell slightly > radius), supports
+//      counting-sorted by cell (x-fastest), stored as float4 (x,y,z,index) so that a run of cells
+//      is one contiguous, coalesced segment;
+//   2. one wave per query: the 3x3x3 cell block is 9 contiguous runs; 64 lanes test 64 candidates
+//      per step with the reference's exact f32 recipe  ((dx*dx + dy*dy) + dz*dz) < r*r,
+//      wave ballot + popcount-prefix compacts the hits into the wave's LDS slab;
+//   3. the slab is bitonic-sorted on the 64-bit key (d2 bits << 32 | index)  (d2 >= 0, so the
+//      IEEE bit pattern is monotonic; ties fall back to the index) and written as one row.
+// Pass A (plan) only counts (-> max_count, the data-dependent width, neighbors.cpp:296-304),
+// pass B (fill) sorts and writes int32 or int64 rows padded with ns (neighbors.cpp:324).
+#include "ws_scan.h"
+#include <vector>
+
+namespace {
+
+struct CloudGrid {        // one per batch element, device resident
+    float lo[3];
+    float inv_cell;
+    int nx, ny, nz;
+    int cell_base;        // first cell of this element in the global cell arrays
+    int cell_cap;         // cells reserved for this element
+    int s_base, s_len;
+    int q_base, q_len;
+};
+
+__global__ __launch_bounds__(1024) void nb_bbox_kernel(const float* __restrict__ pts, CloudGrid* __restrict__ grids,
+                                                        float* __restrict__ bbox /*[nb][6]*/)
+{
+    __shared__ float red[6][16];
+    const CloudGrid g = grids[blockIdx.x];
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = threadIdx.x; i < g.s_len; i += blockDim.x) {
+        const float* p = pts + 3 * (int64_t)(g.s_base + i);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], p[d]); mx[d] = fmaxf(mx[d], p[d]); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[d] = fminf(mn[d], __shfl_xor(mn[d], o, 64));
+            mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o, 64));
+        }
+        if (lane == 0) { red[d][wave] = mn[d]; red[3 + d][wave] = mx[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float v = red[d][0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = d < 3 ? fminf(v, red[d][w]) : fmaxf(v, red[d][w]);
+        bbox[blockIdx.x * 6 + d] = v;
+    }
+}
+
+__global__ void nb_grid_setup_kernel(CloudGrid* __restrict__ grids, const float* __restrict__ bbox, int nb, float radius)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    CloudGrid g = grids[b];
+    if (g.s_len <= 0) {
+        g.lo[0] = g.lo[1] = g.lo[2] = 0.f; g.inv_cell = 1.f; g.nx = g.ny = g.nz = 1;
+        grids[b] = g;
+        return;
+    }
+    const float* bb = bbox + 6 * b;
+    // cell > radius by a margin that dominates the rounding of (v - lo) * inv_cell (dims <= 512)
+    float cell = (radius > 0.f ? radius : 1.f) * 1.001f;
+    int nx, ny, nz;
+    for (;;) {
+        const float inv = 1.0f / cell;
+        nx = (int)floorf((bb[3] - bb[0]) * inv) + 1;
+        ny = (int)floorf((bb[4] - bb[1]) * inv) + 1;
+        nz = (int)floorf((bb[5] - bb[2]) * inv) + 1;
+        if (nx <= 512 && ny <= 512 && nz <= 512 && (int64_t)nx * ny * nz <= (int64_t)g.cell_cap) break;
+        cell *= 1.26f;
+    }
+    g.lo[0] = bb[0]; g.lo[1] = bb[1]; g.lo[2] = bb[2];
+    g.inv_cell = 1.0f / cell;
+    g.nx = nx; g.ny = ny; g.nz = nz;
+    grids[b] = g;
+}
+
+// cell coordinate; clamped so that far-away queries cannot overflow the int conversion
+__device__ __forceinline__ int cell_coord(float v, float lo, float inv)
+{
+    const float t = floorf((v - lo) * inv);
+    return (int)fminf(fmaxf(t, -2.0f), 1.0e6f);
+}
+
+// one thread per support: cell id + histogram
+__global__ __launch_bounds__(256) void nb_bin_count_kernel(const float* __restrict__ pts, const CloudGrid* __restrict__ grids,
+                                                            int nb, int64_t ns, int32_t* __restrict__ cell_of,
+                                                            int32_t* __restrict__ cell_count)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ns; i += (int64_t)gridDim.x * 256) {
+        int b = 0;
+        while (b + 1 < nb && i >= grids[b].s_base + grids[b].s_len) ++b;
+        const CloudGrid& g = grids[b];
+        const float* p = pts + 3 * i;
+        int cx = min(max(cell_coord(p[0], g.lo[0], g.inv_cell), 0), g.nx - 1);
+        int cy = min(max(cell_coord(p[1], g.lo[1], g.inv_cell), 0), g.ny - 1);
+        int cz = min(max(cell_coord(p[2], g.lo[2], g.inv_cell), 0), g.nz - 1);
+        const int c = g.cell_base + (cz * g.ny + cy) * g.nx + cx;
+        cell_of[i] = c;
+        atomicAdd(&cell_count[c], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void nb_bin_fill_kernel(const float* __restrict__ pts, int64_t ns,
+                                                           const int32_t* __restrict__ cell_of,
+                                                           int32_t* __restrict__ cursor, float4* __restrict__ sorted)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ns; i += (int64_t)gridDim.x * 256) {
+        const int pos = atomicAdd(&cursor[cell_of[i]], 1);
+        sorted[pos] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float((int)i));
+    }
+}
+
+// Enumerate the candidates of query (qx,qy,qz): calls f(float4 cand) for all lanes in lock-step;
+// every lane of the wave takes part, `cand.w` carries the global support index; inactive lanes
+// get active=false.
+template <typename F>
+__device__ __forceinline__ void for_each_candidate(const CloudGrid& g, float qx, float qy, float qz,
+                                                   const int32_t* __restrict__ cell_start,
+                                                   const float4* __restrict__ sorted, int lane, F&& f)
+{
+    const int cx = cell_coord(qx, g.lo[0], g.inv_cell);
+    const int cy = cell_coord(qy, g.lo[1], g.inv_cell);
+    const int cz = cell_coord(qz, g.lo[2], g.inv_cell);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    if (x0 > x1) return;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); ++z) {
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); ++y) {
+            const int row = g.cell_base + (z * g.ny + y) * g.nx;
+            const int beg = cell_start[row + x0], end = cell_start[row + x1 + 1];
+            for (int p0 = beg; p0 < end; p0 += 64) {
+                const int p = p0 + lane;
+                const bool active = p < end;
+                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (active) c = sorted[p];
+                f(c, active);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int find_cloud_q(const CloudGrid* __restrict__ grids, int nb, int64_t q)
+{
+    int b = 0;
+    while (b + 1 < nb && q >= grids[b].q_base + grids[b].q_len) ++b;
+    return b;
+}
+
+// exact reference recipe (nanoflann.hpp:432-440): result = 0; result += diff*diff, diff = query - support
+__device__ __forceinline__ float ref_d2(float qx, float qy, float qz, const float4& c)
+{
+    const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+    float r = dx * dx;
+    r = r + dy * dy;
+    r = r + dz * dz;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void nb_count_kernel(const float* __restrict__ queries, int64_t nq,
+                                                        const CloudGrid* __restrict__ grids, int nb,
+                                                        const int32_t* __restrict__ cell_start,
+                                                        const float4* __restrict__ sorted, float r2,
+                                                        int32_t* __restrict__ counts, int32_t* __restrict__ max_count)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int local_max = 0;
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
+        const int b = find_cloud_q(grids, nb, q);
+        const CloudGrid g = grids[b];
+        const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
+        int cnt = 0;
+        if (g.s_len > 0) {
+            for_each_candidate(g, qx, qy, qz, cell_start, sorted, lane, [&](const float4& c, bool active) {
+                const bool hit = active && ref_d2(qx, qy, qz, c) < r2;
+                cnt += __builtin_popcountll(__ballot(hit));
+            });
+        }
+        if (lane == 0) counts[q] = cnt;
+        local_max = max(local_max, cnt);
+    }
+    if (lane == 0 && local_max > 0) atomicMax(max_count, local_max);
+}
+
+template <int CAP, typename OutT>
+__global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ queries, int64_t nq,
+                                                       const CloudGrid* __restrict__ grids, int nb,
+                                                       const int32_t* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, float r2, int64_t ns,
+                                                       int width, OutT* __restrict__ out)
+{
+    __shared__ unsigned long long slab_all[4][CAP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long* slab = slab_all[wave];
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
+        const int b = find_cloud_q(grids, nb, q);
+        const CloudGrid g = grids[b];
+        const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
+        int cnt = 0;
+        if (g.s_len > 0) {
+            for_each_candidate(g, qx, qy, qz, cell_start, sorted, lane, [&](const float4& c, bool active) {
+                const float d2 = ref_d2(qx, qy, qz, c);
+                const bool hit = active && d2 < r2;
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const int pos = cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (pos < CAP)
+                        slab[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c.w);
+                }
+                cnt += __builtin_popcountll(m);
+            });
+        }
+        cnt = min(cnt, CAP);
+        int m = 64;
+        while (m < cnt) m <<= 1;
+        for (int i = cnt + lane; i < m; i += 64) slab[i] = ~0ull;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (cnt > 1) {
+            for (int k = 2; k <= m; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = lane; t < (m >> 1); t += 64) {
+                        // t-th compare-exchange of this stage: insert a 0 bit at position log2(j)
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const int l = i | j;
+                        const unsigned long long a = slab[i], bb = slab[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > bb) == up) { slab[i] = bb; slab[l] = a; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        for (int j = lane; j < width; j += 64)
+            out[q * width + j] = j < cnt ? (OutT)(unsigned)(slab[j] & 0xffffffffull) : (OutT)ns;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return WS_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 4 + 64;
+        WS_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+        cap = want;
+        return WS_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct ws_neighbors_ws {
+    DevBuf<CloudGrid> grids;
+    DevBuf<float> bbox;
+    DevBuf<int32_t> cell_of, cell_start, cursor, counts, scan_scratch, max_count;
+    DevBuf<float4> sorted;
+    // state of the last plan
+    const float* queries = nullptr;
+    int64_t nq = 0, ns = 0;
+    int nb = 0;
+    float r2 = 0.f;
+    int max_count_host = 0;
+};
+
+extern "C" {
+
+int ws_neighbors_ws_create(ws_neighbors_ws** ws)
+{
+    WS_REQUIRE(ws, "NULL argument");
+    *ws = new ws_neighbors_ws();
+    return WS_OK;
+}
+
+void ws_neighbors_ws_destroy(ws_neighbors_ws* ws)
+{
+    if (!ws) return;
+    ws->grids.release(); ws->bbox.release(); ws->cell_of.release(); ws->cell_start.release();
+    ws->cursor.release(); ws->counts.release(); ws->scan_scratch.release(); ws->max_count.release();
+    ws->sorted.release();
+    delete ws;
+}
+
+int ws_radius_neighbors_plan(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
+                             int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                             float radius, int32_t* h_max_count, void* stream)
+{
+    WS_REQUIRE(ws && h_q_lens && h_s_lens && h_max_count, "NULL argument");
+    WS_REQUIRE(nb >= 1 && nq >= 0 && ns >= 0, "bad sizes nb=%d nq=%lld ns=%lld", nb, (long long)nq, (long long)ns);
+    WS_REQUIRE(ns < (1ll << 30) && nq < (1ll << 31), "point count exceeds int32 range");
+    *h_max_count = 0;
+    ws->max_count_host = 0;
+    ws->nq = 0;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<CloudGrid> hg((size_t)nb);
+    int64_t qsum = 0, ssum = 0, cells = 0;
+    for (int b = 0; b < nb; ++b) {
+        WS_REQUIRE(h_q_lens[b] >= 0 && h_s_lens[b] >= 0, "negative batch length");
+        CloudGrid& g = hg[(size_t)b];
+        g = CloudGrid{};
+        g.q_base = (int)qsum; g.q_len = h_q_lens[b];
+        g.s_base = (int)ssum; g.s_len = h_s_lens[b];
+        g.cell_base = (int)cells;
+        g.cell_cap = 4 * h_s_lens[b] + 64;
+        cells += g.cell_cap;
+        qsum += h_q_lens[b]; ssum += h_s_lens[b];
+    }
+    WS_REQUIRE(qsum == nq && ssum == ns, "batch lengths do not sum to the point counts (%lld/%lld, %lld/%lld)",
+               (long long)qsum, (long long)nq, (long long)ssum, (long long)ns);
+    WS_REQUIRE(cells < (1ll << 31) - 2, "too many grid cells");
+    if (nq == 0 || ns == 0) return ws_fail(WS_ERR_EMPTY, "Error");   // wrapper.cpp:201-205
+    WS_REQUIRE(queries && supports, "NULL argument");
+
+    int rc;
+    if ((rc = ws->grids.ensure((size_t)nb))) return rc;
+    if ((rc = ws->bbox.ensure((size_t)nb * 6))) return rc;
+    if ((rc = ws->cell_of.ensure((size_t)ns))) return rc;
+    if ((rc = ws->cell_start.ensure((size_t)cells + 2))) return rc;
+    if ((rc = ws->cursor.ensure((size_t)cells + 2))) return rc;
+    if ((rc = ws->counts.ensure((size_t)nq))) return rc;
+    if ((rc = ws->scan_scratch.ensure((size_t)ws_scan_scratch_items(cells + 1)))) return rc;
+    if ((rc = ws->max_count.ensure(1))) return rc;
+    if ((rc = ws->sorted.ensure((size_t)ns))) return rc;
+
+    WS_HIP(hipMemcpyAsync(ws->grids.p, hg.data(), sizeof(CloudGrid) * (size_t)nb, hipMemcpyHostToDevice, st));
+    WS_HIP(hipStreamSynchronize(st));   // hg is a stack-lifetime staging buffer
+    nb_bbox_kernel<<<nb, 1024, 0, st>>>(supports, ws->grids.p, ws->bbox.p);
+    WS_LAUNCH_CHECK();
+    nb_grid_setup_kernel<<<(nb + 63) / 64, 64, 0, st>>>(ws->grids.p, ws->bbox.p, nb, radius);
+    WS_LAUNCH_CHECK();
+    WS_HIP(hipMemsetAsync(ws->cell_start.p, 0, sizeof(int32_t) * (size_t)(cells + 2), st));
+    WS_HIP(hipMemsetAsync(ws->max_count.p, 0, sizeof(int32_t), st));
+    nb_bin_count_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(supports, ws->grids.p, nb, ns, ws->cell_of.p, ws->cell_start.p);
+    WS_LAUNCH_CHECK();
+    if ((rc = ws_exclusive_scan_i32(ws->cell_start.p, ws->cell_start.p, cells, ws->scan_scratch.p, st))) return rc;
+    WS_HIP(hipMemcpyAsync(ws->cursor.p, ws->cell_start.p, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToDevice, st));
+    nb_bin_fill_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(supports, ns, ws->cell_of.p, ws->cursor.p, ws->sorted.p);
+    WS_LAUNCH_CHECK();
+    const float r2 = radius * radius;   // neighbors.cpp:226
+    nb_count_kernel<<<ws_grid(nq, 4), 256, 0, st>>>(queries, nq, ws->grids.p, nb, ws->cell_start.p, ws->sorted.p, r2,
+                                                    ws->counts.p, ws->max_count.p);
+    WS_LAUNCH_CHECK();
+    int32_t mc = 0;
+    WS_HIP(hipMemcpyAsync(&mc, ws->max_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    WS_HIP(hipStreamSynchronize(st));
+    ws->queries = queries; ws->nq = nq; ws->ns = ns; ws->nb = nb; ws->r2 = r2; ws->max_count_host = mc;
+    *h_max_count = mc;
+    if (mc == 0) return ws_fail(WS_ERR_EMPTY, "Error");
+    return WS_OK;
+}
+
+int ws_radius_neighbors_fill(ws_neighbors_ws* ws, int32_t width, int32_t* out_i32, int64_t* out_i64, void* stream)
+{
+    WS_REQUIRE(ws && ws->nq > 0 && ws->max_count_host > 0, "no successful plan to fill from");
+    WS_REQUIRE((out_i32 != nullptr) != (out_i64 != nullptr), "exactly one of out_i32 / out_i64 must be given");
+    WS_REQUIRE(width >= 1 && width <= ws->max_count_host, "width %d outside [1, max_count=%d]", width, ws->max_count_host);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ws_grid(ws->nq, 4);
+    const int mc = ws->max_count_host;
+#define WS_NB_FILL(CAP)                                                                                          \
+    do {                                                                                                         \
+        if (out_i32)                                                                                             \
+            nb_fill_kernel<CAP, int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb,          \
+                                                               ws->cell_start.p, ws->sorted.p, ws->r2, ws->ns, width, out_i32); \
+        else                                                                                                     \
+            nb_fill_kernel<CAP, int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb,          \
+                                                               ws->cell_start.p, ws->sorted.p, ws->r2, ws->ns, width, out_i64); \
+    } while (0)
+    if (mc <= 128) WS_NB_FILL(128);
+    else if (mc <= 512) WS_NB_FILL(512);
+    else if (mc <= 2048) WS_NB_FILL(2048);
+    else return ws_fail(WS_ERR_UNSUPPORTED, "max neighbour count %d exceeds the 2048-entry sort slab", mc);
+#undef WS_NB_FILL
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+const int32_t* ws_radius_neighbors_counts(const ws_neighbors_ws* ws) { return ws ? ws->counts.p : nullptr; }
+
+}  // extern "C"

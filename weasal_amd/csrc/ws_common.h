@@ -1,0 +1,61 @@
+// weasal_amd/csrc/ws_common.h -- shared host/device helpers of libweasal_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/weasal_hip.h"
+
+#define WS_WAVE 64
+
+// thread-local error message (ws_last_error)
+char* ws_errbuf();
+inline int ws_fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ws_errbuf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define WS_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return ws_fail(WS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                           __FILE__, __LINE__);                                          \
+    } while (0)
+
+#define WS_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return ws_fail(WS_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define WS_LAUNCH_CHECK() WS_HIP(hipGetLastError())
+
+static inline int64_t ws_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// grid size for wave-per-item / grid-stride kernels: enough workgroups to fill 256 CUs a few
+// times over, never more than the work.
+static inline int ws_grid(int64_t items, int per_block, int max_blocks = 256 * 16)
+{
+    int64_t b = ws_ceil_div(items, per_block);
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int ws_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ float ws_readlane_f(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float ws_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif

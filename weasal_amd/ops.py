@@ -1,0 +1,346 @@
+"""Device-tensor operators over the C ABI (include/weasal_hip.h).
+
+PyTorch is used here for device memory, streams and autograd bookkeeping only: every
+function below launches hand-written HIP kernels from libweasal_hip.so through ctypes, on
+torch's current stream.  CPU tensors are rejected -- there is no CPU path in the product
+(the CPU restatement lives in oracle/ and is test infrastructure).
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+INFLUENCE = {"linear": 0, "constant": 1, "gaussian": 2}
+AGGREGATION = {"sum": 0, "closest": 1}
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.WeasalHipError(
+                "weasal_amd operators run on the GPU only (got a %s tensor); move the batch to "
+                "cuda -- there is no CPU fallback" % t.device)
+
+
+def _f32c(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# transposed neighbour tables, cached per index tensor (one per layer and batch; every block of
+# the layer and both pooling helpers reuse it)
+# ------------------------------------------------------------------------------------------------
+class TransposedTable:
+    __slots__ = ("offsets", "pairs", "nq", "h", "ns")
+
+    def __init__(self, inds, ns):
+        _need_cuda(inds)
+        assert inds.dtype == torch.int64 and inds.dim() == 2 and inds.is_contiguous()
+        nq, h = inds.shape
+        lib = _lib.lib()
+        self.nq, self.h, self.ns = nq, h, ns
+        self.offsets = torch.empty(ns + 2, dtype=torch.int32, device=inds.device)
+        self.pairs = torch.empty(max(nq * h, 1), dtype=torch.int32, device=inds.device)
+        scratch = torch.empty(lib.ws_transpose_scratch_bytes(nq, h, ns), dtype=torch.uint8, device=inds.device)
+        check(lib.ws_transpose_build(ptr(inds), nq, h, ns, ptr(self.offsets), ptr(self.pairs), ptr(scratch),
+                                     current_stream()))
+
+
+_tables = collections.OrderedDict()
+_TABLES_MAX = 32
+
+
+def transposed_table(inds, ns):
+    """Table for `inds` [nq,h] over `ns` supports, cached per index tensor.  The entry keeps a
+    reference to the tensor, so its memory (the cache key) cannot be recycled while cached; the
+    cache is a small LRU (a batch needs 3 tables per layer)."""
+    key = (inds.data_ptr(), tuple(inds.shape), ns, inds._version)
+    hit = _tables.get(key)
+    if hit is not None:
+        _tables.move_to_end(key)
+        return hit[1]
+    table = TransposedTable(inds, ns)
+    _tables[key] = (inds, table)
+    while len(_tables) > _TABLES_MAX:
+        _tables.popitem(last=False)
+    return table
+
+
+def clear_table_cache():
+    _tables.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# KPConv gather (K3 / K4 / K6)
+# ------------------------------------------------------------------------------------------------
+class _KPConvGather(torch.autograd.Function):
+    """wf[q,k,c] = sum_h w(q,h,k) x[inds[q,h],c]   (reference: models/blocks.py:278-367)"""
+
+    @staticmethod
+    def forward(ctx, x, deformed_kp, modulations, q_pts, s_pts, inds, kernel_points, extent, influence,
+                aggregation, want_min_d2):
+        lib = _lib.lib()
+        _need_cuda(x, q_pts, s_pts, inds, kernel_points)
+        x = x.contiguous()
+        nq, h = inds.shape
+        ns, ci = x.shape
+        k = kernel_points.shape[0]
+        wf = torch.empty((nq, k, ci), dtype=torch.float32, device=x.device)
+        min_d2 = torch.empty((nq, k), dtype=torch.float32, device=x.device) if want_min_d2 else None
+        dkp = deformed_kp.contiguous() if deformed_kp is not None else None
+        mod = modulations.contiguous() if modulations is not None else None
+        check(lib.ws_kpconv_gather_fwd(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci,
+                                       ptr(kernel_points), k, ptr(dkp), ptr(mod), float(extent),
+                                       influence, aggregation, ptr(wf), ptr(min_d2), current_stream()))
+        ctx.save_for_backward(x, dkp, mod, q_pts, s_pts, inds, kernel_points)
+        ctx.cfg = (float(extent), influence, aggregation)
+        return wf, min_d2
+
+    @staticmethod
+    def backward(ctx, dwf, d_min_d2):
+        lib = _lib.lib()
+        x, dkp, mod, q_pts, s_pts, inds, kernel_points = ctx.saved_tensors
+        extent, influence, aggregation = ctx.cfg
+        nq, h = inds.shape
+        ns, ci = x.shape
+        k = kernel_points.shape[0]
+        dwf = dwf.contiguous()
+        dx = d_dkp = d_mod = None
+        if ctx.needs_input_grad[0]:
+            table = transposed_table(inds, ns)
+            dx = torch.empty_like(x)
+            check(lib.ws_kpconv_gather_bwd_x(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(table.offsets),
+                                             ptr(table.pairs), ptr(dwf), ci, ptr(kernel_points), k, ptr(dkp),
+                                             ptr(mod), extent, influence, aggregation, ptr(dx), current_stream()))
+        if dkp is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            d_dkp = torch.empty_like(dkp)
+            d_mod = torch.empty_like(mod) if mod is not None else None
+            dmin = d_min_d2.contiguous() if d_min_d2 is not None else None
+            check(lib.ws_kpconv_gather_bwd_geom(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(dwf),
+                                                ptr(kernel_points), k, ptr(dkp), ptr(mod), ptr(dmin), extent,
+                                                influence, aggregation, ptr(d_dkp), ptr(d_mod), current_stream()))
+        return dx, d_dkp, d_mod, None, None, None, None, None, None, None, None
+
+
+def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linear", aggregation="sum",
+                  deformed_kp=None, modulations=None, want_min_d2=False):
+    """Fused neighbour gather + kernel-point influence + aggregate -> wf [nq, K, ci] (and min_d2)."""
+    q_pts = _f32c(q_pts)
+    s_pts = _f32c(s_pts)
+    kernel_points = _f32c(kernel_points)
+    inds = inds.contiguous()
+    if inds.dtype != torch.int64:
+        inds = inds.to(torch.int64)
+    return _KPConvGather.apply(x, deformed_kp, modulations, q_pts, s_pts, inds, kernel_points, extent,
+                               INFLUENCE[influence], AGGREGATION[aggregation], want_min_d2)
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling helpers (K7)
+# ------------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, inds):
+        lib = _lib.lib()
+        _need_cuda(x, inds)
+        x = x.contiguous()
+        ns, c = x.shape
+        nq, h = inds.shape
+        out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
+        arg = torch.empty((nq, c), dtype=torch.int32, device=x.device)
+        check(lib.ws_max_pool_fwd(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), ptr(arg), current_stream()))
+        ctx.save_for_backward(arg, inds)
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.lib()
+        arg, inds = ctx.saved_tensors
+        nq, c = arg.shape
+        h = inds.shape[1]
+        table = transposed_table(inds, ctx.ns)
+        dx = torch.empty((ctx.ns, c), dtype=torch.float32, device=dy.device)
+        dy = dy.contiguous()
+        check(lib.ws_max_pool_bwd(ptr(dy), ptr(arg), nq, h, c, ptr(table.offsets), ptr(table.pairs), ctx.ns,
+                                  ptr(dx), current_stream()))
+        return dx, None
+
+
+class _ClosestPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, inds):
+        lib = _lib.lib()
+        _need_cuda(x, inds)
+        x = x.contiguous()
+        ns, c = x.shape
+        nq, h = inds.shape
+        out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
+        check(lib.ws_closest_pool_fwd(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), current_stream()))
+        ctx.save_for_backward(inds)
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.lib()
+        (inds,) = ctx.saved_tensors
+        nq, h = inds.shape
+        c = dy.shape[1]
+        table = transposed_table(inds, ctx.ns)
+        dx = torch.empty((ctx.ns, c), dtype=torch.float32, device=dy.device)
+        dy = dy.contiguous()
+        check(lib.ws_closest_pool_bwd(ptr(dy), nq, h, c, ptr(table.offsets), ptr(table.pairs), ctx.ns, ptr(dx),
+                                      current_stream()))
+        return dx, None
+
+
+def _as_index(inds):
+    inds = inds.contiguous()
+    return inds if inds.dtype == torch.int64 else inds.to(torch.int64)
+
+
+def max_pool(x, inds):
+    """reference: models/blocks.py:95-111"""
+    return _MaxPool.apply(x, _as_index(inds))
+
+
+def closest_pool(x, inds):
+    """reference: models/blocks.py:80-92"""
+    return _ClosestPool.apply(x, _as_index(inds))
+
+
+# ------------------------------------------------------------------------------------------------
+# native geometry on device tensors (K1 / K2)
+# ------------------------------------------------------------------------------------------------
+class _Workspaces:
+    """one neighbour and one subsample workspace per device (grow-only device scratch)"""
+
+    def __init__(self):
+        self.nb = {}
+        self.sub = {}
+
+    def neighbors(self, device):
+        key = torch.device(device).index or 0
+        if key not in self.nb:
+            import ctypes as C
+            h = C.c_void_p()
+            check(_lib.lib().ws_neighbors_ws_create(C.byref(h)))
+            self.nb[key] = h
+        return self.nb[key]
+
+    def subsample(self, device):
+        key = torch.device(device).index or 0
+        if key not in self.sub:
+            import ctypes as C
+            h = C.c_void_p()
+            check(_lib.lib().ws_subsample_ws_create(C.byref(h)))
+            self.sub[key] = h
+        return self.sub[key]
+
+
+_ws = _Workspaces()
+
+
+class _DevView:
+    """zero-copy int32 view of workspace memory (consumed through __cuda_array_interface__)"""
+
+    def __init__(self, addr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(addr), True),
+                                         "version": 2, "strides": None}
+
+
+def _host_lens(lens):
+    if isinstance(lens, torch.Tensor):
+        lens = lens.detach().cpu().numpy()
+    return np.ascontiguousarray(lens, dtype=np.int32)
+
+
+def radius_neighbors(queries, supports, q_lens, s_lens, radius, limit=None, dtype=torch.int64,
+                     return_counts=False):
+    """Batched radius search on device tensors (reference: cpp_neighbors.batch_query,
+    neighbors.cpp:211-332).  q_lens/s_lens: host sequences.  Returns [Nq, min(max_count, limit)]
+    of `dtype` (int32 like the reference module, or int64 like datasets/common.py:551 makes it)."""
+    import ctypes as C
+    lib = _lib.lib()
+    _need_cuda(queries, supports)
+    q = _f32c(queries)
+    s = _f32c(supports)
+    ql, sl = _host_lens(q_lens), _host_lens(s_lens)
+    if ql.shape[0] != sl.shape[0]:
+        raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
+    ws = _ws.neighbors(q.device)
+    mc = C.c_int32(0)
+    with torch.cuda.device(q.device):
+        check(lib.ws_radius_neighbors_plan(ws, ptr(q), q.shape[0], ptr(s), s.shape[0],
+                                           C.c_void_p(ql.ctypes.data), C.c_void_p(sl.ctypes.data), ql.shape[0],
+                                           float(np.float32(radius)), C.byref(mc), current_stream()))
+        width = mc.value if limit is None else max(1, min(mc.value, int(limit)))
+        out = torch.empty((q.shape[0], width), dtype=dtype, device=q.device)
+        if dtype == torch.int32:
+            check(lib.ws_radius_neighbors_fill(ws, width, ptr(out), None, current_stream()))
+        elif dtype == torch.int64:
+            check(lib.ws_radius_neighbors_fill(ws, width, None, ptr(out), current_stream()))
+        else:
+            raise ValueError("dtype must be torch.int32 or torch.int64")
+        if return_counts:
+            counts = torch.as_tensor(_DevView(lib.ws_radius_neighbors_counts(ws), q.shape[0]),
+                                     device=q.device).clone()
+            return out, counts
+    return out
+
+
+def grid_subsample(points, lens, dl, max_p=0, features=None, labels=None, reference_order=True,
+                   return_keys=False):
+    """Batched grid subsampling on device tensors (reference: cpp_subsampling.subsample_batch,
+    grid_subsampling.cpp:109-211).  Returns (points [M,3], lens (numpy int32 [B]) [, features][, labels])."""
+    import ctypes as C
+    lib = _lib.lib()
+    _need_cuda(points, features, labels)
+    p = _f32c(points)
+    hl = _host_lens(lens)
+    nb = hl.shape[0]
+    ws = _ws.subsample(p.device)
+    out_lens = np.zeros(nb, dtype=np.int32)
+    m = C.c_int64(0)
+    f = _f32c(features)
+    lab = None
+    ld = 0
+    if labels is not None:
+        lab = labels.detach().to(torch.int32).contiguous()
+        ld = 1 if lab.dim() == 1 else lab.shape[1]
+    fd = f.shape[1] if f is not None else 0
+    with torch.cuda.device(p.device):
+        check(lib.ws_grid_subsample_plan(ws, ptr(p), p.shape[0], C.c_void_p(hl.ctypes.data), nb,
+                                         float(np.float32(dl)), int(max_p), 0 if reference_order else 1,
+                                         C.c_void_p(out_lens.ctypes.data), C.byref(m), current_stream()))
+        M = m.value
+        out_p = torch.empty((M, 3), dtype=torch.float32, device=p.device)
+        out_f = torch.empty((M, fd), dtype=torch.float32, device=p.device) if f is not None else None
+        out_l = torch.empty((M, ld), dtype=torch.int32, device=p.device) if lab is not None else None
+        keys = torch.empty(M, dtype=torch.int64, device=p.device) if return_keys else None
+        cnts = torch.empty(M, dtype=torch.int32, device=p.device) if return_keys else None
+        check(lib.ws_grid_subsample_fill(ws, ptr(f), fd, ptr(lab), ld, ptr(out_p), ptr(out_f), ptr(out_l),
+                                         ptr(keys), ptr(cnts), current_stream()))
+    res = [out_p, out_lens]
+    if f is not None:
+        res.append(out_f)
+    if lab is not None:
+        res.append(out_l)
+    if return_keys:
+        res += [keys, cnts]
+    return tuple(res)
+
+
+def rotate_clouds(points, lens_dev, rot, transpose=False):
+    """out[i] = points[i] @ R[b] (or R[b].T) in the f32 order of datasets/common.py:116-119,131-135"""
+    lib = _lib.lib()
+    _need_cuda(points, lens_dev, rot)
+    p = _f32c(points)
+    out = torch.empty_like(p)
+    check(lib.ws_rotate_clouds(ptr(p), p.shape[0], ptr(lens_dev), lens_dev.shape[0], ptr(rot.contiguous()),
+                               1 if transpose else 0, ptr(out), current_stream()))
+    return out
