@@ -249,7 +249,7 @@ class _DevView:
     """zero-copy int32 view of workspace memory (consumed through __cuda_array_interface__)"""
 
     def __init__(self, addr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(addr), True),
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(addr), False),
                                          "version": 2, "strides": None}
 
 
