@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- points/sec of one KP-FCNN training step on synthetic DALES-shaped spheres.
+
+One "step" = one pass of the whole hot path over one batch that is already resident in HBM:
+  input pyramid on the GPU (13 radius-neighbour searches + 4 grid subsamplings, HIP)
+  -> KPFCNN forward -> loss -> backward -> [flat RCCL all-reduce when N > 1]
+  -> clip_grad_value_ -> SGD step.
+`value` = level-0 points of all ranks per second (weak scaling: every rank owns its own batch of
+8 x 50k-point spheres, BASELINE.json configs[2]; configs[3] is the same per rank on 8 GPUs).
+
+Besides the contract line this prints, in the same JSON object:
+  roofline      the fused KPConv gather kernel (K3) of the largest layer (enc1: N=400k, H=59, 32->32):
+                algorithmic bytes B_fwd / average launch duration measured with
+                HIP events on the launch stream inside the timed region, against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU path (reference geometry core from oracle/_ref when present, else the port;
+                plain-torch KPConv restatement) timed on this box's host cores on ONE sphere.
+
+Launch: `python bench.py` (1 GPU) or
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def b_fwd(n, h, ci, co):
+    """algorithmic bytes of one fused KPConv forward"""
+    return n * h * (8 + 12 + 4 * ci) + n * (12 + 4 * co) + 60 * ci * co + 180
+
+
+class KernelTimer:
+    """HIP-event timing of selected launches on torch's current stream (= the launch stream)"""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def begin(self, key):
+        if not self.enabled:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (key, e0, e1)
+
+    def end(self, tok):
+        if tok is None:
+            return
+        key, e0, e1 = tok
+        e1.record()
+        self.records.setdefault(key, []).append((e0, e1))
+
+    def summary(self):
+        out = {}
+        for key, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[key] = (float(np.mean(ms)), len(ms))
+        return out
+
+
+def cpu_baseline(cfg_cls, wl, threads):
+    """Reference CPU path on a bounded sample: ONE sphere of the workload through
+    (a) the pyramid on the CPU geometry core, single thread like one DataLoader worker,
+    (b) KPFCNN forward + loss + backward in plain torch on all host threads."""
+    from oracle import geom, kpconv_ref, pyramid_ref
+    from weasal_amd.architectures import KPFCNN
+    from weasal_amd.pyramid import PyramidBatch
+    from weasal_amd.synthetic import make_inputs
+    torch.set_num_threads(threads)
+    cfg = cfg_cls()
+    kind = "ref" if geom.have_ref() else "port"
+    pts, feats, labels, lens = make_inputs(12345, 1, wl["points"], wl["radius"], cfg.in_features_dim)
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    li = pyramid_ref.segmentation_inputs(cfg, pts, feats, labels, lens, wl["limits"], kind=kind)
+    t_pyr = time.perf_counter() - t0
+    batch = PyramidBatch([torch.from_numpy(np.ascontiguousarray(a)) for a in li])
+    net = KPFCNN(cfg, np.arange(9), [])
+    net.train()
+    with kpconv_ref.cpu_reference_mode():
+        t0 = time.perf_counter()
+        out = net(batch, cfg)
+        loss = net.loss(out, batch.labels)
+        loss.backward()
+        t_model = time.perf_counter() - t0
+    n = int(lens.sum())
+    return {"value": n / (t_pyr + t_model), "unit": "points/s", "cores": threads,
+            "kind": "reference" if kind == "ref" else "port",
+            "sample": "1 sphere x %d pts: pyramid %.2fs on 1 thread (%s geometry core) + KPFCNN fwd+bwd %.2fs "
+                      "in plain torch (oracle/kpconv_ref.py restatement of models/blocks.py) on %d threads"
+                      % (n, t_pyr, "oracle/_ref = the reference's own C++" if kind == "ref" else "oracle port", t_model, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct-batches", type=int, default=4)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from weasal_amd import config as wcfg, dp, ops, pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    from weasal_amd.trainer import make_optimizer, train_step
+
+    rank, local_rank, world = dp.init_from_env()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    wl = synthetic.WORKLOADS[args.workload]
+    cfg_cls = getattr(wcfg, wl["config"])
+    cfg = cfg_cls()
+    np.random.seed(1234 + rank)
+    torch.manual_seed(1234)            # same initial replica everywhere
+    net = KPFCNN(cfg, np.arange(9), []).to(dev)
+    net.train()
+    dp.broadcast_parameters(net)
+    opt = make_optimizer(net, cfg)
+    sync = dp.GradSync() if world > 1 else None
+
+    # inputs resident in HBM before the timed region (seed = 1000*rank + step)
+    nd = max(1, min(args.distinct_batches, args.steps + args.warmup))
+    inputs = []
+    for i in range(nd):
+        pts, feats, labels, lens = synthetic.make_inputs(1000 * rank + i, wl["spheres"], wl["points"], wl["radius"],
+                                                         cfg.in_features_dim)
+        inputs.append((torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev),
+                       torch.from_numpy(labels).to(dev), lens))
+    n_points = int(inputs[0][3].sum())
+
+    timer = KernelTimer()
+    ops.set_kernel_timer(timer)
+
+    def step(i):
+        pts, feats, labels, lens = inputs[i % nd]
+        batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
+        loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync)
+        return loss
+
+    for i in range(args.warmup):
+        tw = time.perf_counter()
+        step(i)
+        torch.cuda.synchronize()
+        if rank == 0:   # progress on stderr (untimed region) so that a long run is visibly alive
+            print("[bench] warmup step %d: %.1f ms" % (i, 1e3 * (time.perf_counter() - tw)), file=sys.stderr, flush=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = 1000.0 * dt / args.steps
+        res = {"metric": "points/sec fwd+bwd KPFCNN on DALES spheres; achieved HBM GB/s on KPConv gather",
+               "value": world * n_points * args.steps / dt, "unit": "points/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": wl["name"] + ", fp32, step = GPU pyramid + fwd + loss + bwd"
+                          + (" + RCCL grad all-reduce" if world > 1 else "") + " + SGD",
+                          "points_per_step_per_gpu": n_points, "parallelism": "dp%d" % world,
+                          "final_loss": float(loss.item())}}
+        # ---- roofline of the fused KPConv gather kernel on the largest layer
+        summ = timer.summary()
+        fwd = {k: v for k, v in summ.items() if k[0] == "kpconv_gather_fwd"}
+        if fwd:
+            ci_dom = 32 if args.workload == "dales" else 16
+            cand = [k for k in fwd if k[3] == ci_dom]
+            key = max(cand or list(fwd), key=lambda k: k[1] * k[2] * k[3])
+            ms_k, count = fwd[key]
+            _, nq, h, ci = key
+            bytes_alg = b_fwd(nq, h, ci, ci)
+            achieved = bytes_alg / (ms_k * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("kpconv_gather_fwd_enc1_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "hbm", "kernel": "kpconv_gather_fwd_kernel<15,32> (enc1: N=%d, H=%d, Ci=%d)" % (nq, h, ci),
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": ms_k, "launches_timed": count}
+            res["kernels_ms"] = {"%s N=%d H=%d C=%d" % k: round(v[0], 4) for k, v in sorted(summ.items())}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg_cls, wl, min(os.cpu_count() or 1, 16))
+            except Exception as e:   # the baseline is a report, never a reason to lose the GPU line
+                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,3 +61,23 @@ def test_port_vs_reference_build():
         a = geom.subsample_batch(p, l, sampleDl=dl, kind="port")
         b = geom.subsample_batch(p, l, sampleDl=dl, kind="ref")
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_pyramid_vs_golden():
+    """the CPU pyramid restatement reproduces the reference's segmentation_inputs (golden g7)"""
+    from oracle import pyramid_ref
+    from test_oracle_cpu_kpconv import _small_config
+    g = golden("g7_pyramid.npz")
+    np.random.seed(int(g["np_seed"]))
+    li = pyramid_ref.segmentation_inputs(_small_config(), g["points"], g["features"], g["labels"], g["lens"],
+                                         list(g["limits"]))
+    L = 5
+    for l in range(L):
+        assert np.array_equal(li[l], g["points_%d" % l])
+        assert np.array_equal(li[4 * L + l], g["lengths_%d" % l])
+        pts_l = g["points_%d" % l]
+        assert_neighbors_equal(pts_l, pts_l, li[L + l], g["neighbors_%d" % l], False)
+        if l < L - 1:
+            nxt = g["points_%d" % (l + 1)]
+            assert_neighbors_equal(nxt, pts_l, li[2 * L + l], g["pools_%d" % l], False)
+            assert_neighbors_equal(pts_l, nxt, li[3 * L + l], g["upsamples_%d" % l], False)

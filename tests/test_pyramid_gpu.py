@@ -1,0 +1,76 @@
+"""GPU: the device pyramid against the reference's segmentation_inputs (golden g7) and the whole
+network forward/backward/SGD step against golden g8 (the reference's KPFCNN on that pyramid)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_neighbors_equal, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+    from test_oracle_cpu_kpconv import _small_config
+    return _small_config()
+
+
+def test_pyramid_vs_golden(gpu):
+    from weasal_amd import pyramid
+    g = golden("g7_pyramid.npz")
+    cfg = _cfg()
+    np.random.seed(int(g["np_seed"]))
+    li = pyramid.segmentation_inputs(cfg, torch.from_numpy(g["points"]).to(gpu), torch.from_numpy(g["features"]).to(gpu),
+                                     torch.from_numpy(g["labels"]).to(gpu), g["lens"], list(g["limits"]))
+    L = 5
+    assert len(li) == 5 * L + 2
+    for l in range(L):
+        assert np.array_equal(li[l].cpu().numpy(), g["points_%d" % l]), l
+        assert np.array_equal(li[4 * L + l].cpu().numpy(), g["lengths_%d" % l])
+    for l in range(L):
+        pts_l = g["points_%d" % l]
+        got = li[L + l].cpu().numpy()
+        assert got.dtype == np.int64
+        assert_neighbors_equal(pts_l, pts_l, got, g["neighbors_%d" % l], False)
+        if l < L - 1:
+            nxt = g["points_%d" % (l + 1)]
+            assert_neighbors_equal(nxt, pts_l, li[2 * L + l].cpu().numpy(), g["pools_%d" % l], False)
+            assert_neighbors_equal(pts_l, nxt, li[3 * L + l].cpu().numpy(), g["upsamples_%d" % l], False)
+        else:
+            assert li[2 * L + l].shape == (0, 1) and li[3 * L + l].shape == (0, 1)
+
+
+def test_kpfcnn_step_vs_golden(gpu):
+    from weasal_amd import pyramid
+    from weasal_amd.architectures import KPFCNN
+    from weasal_amd.trainer import make_optimizer, train_step
+    g8, g7 = golden("g8_kpfcnn.npz"), golden("g7_pyramid.npz")
+    cfg = _cfg()
+    np.random.seed(0)
+    net = KPFCNN(cfg, np.arange(9), [])
+    sd = {k[4:]: torch.from_numpy(g8[k]) for k in g8.files if k.startswith("sd0/")}
+    net.load_state_dict(sd, strict=False)
+    net.to(gpu).train()
+    L = 5
+    flat = ([g7["points_%d" % l] for l in range(L)] + [g7["neighbors_%d" % l] for l in range(L)]
+            + [g7["pools_%d" % l] for l in range(L)] + [g7["upsamples_%d" % l] for l in range(L)]
+            + [g7["lengths_%d" % l] for l in range(L)] + [g7["features"], g7["labels"]])
+    batch = pyramid.PyramidBatch([torch.from_numpy(np.ascontiguousarray(a)) for a in flat]).to(gpu)
+    opt = make_optimizer(net, cfg)
+    loss, out = train_step(net, opt, batch, cfg)
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+    assert rel(out.detach().cpu().numpy(), g8["logits"]) < 1e-4
+    assert abs(loss.item() - float(g8["loss"])) < 1e-5
+    params = dict(net.named_parameters())
+    for k in g8.files:
+        if k.startswith("grad/"):
+            assert rel(params[k[5:]].grad.cpu().numpy(), g8[k]) < 1e-3, k
+    sd1 = net.state_dict()
+    for k in g8.files:
+        if k.startswith("sd1/"):
+            assert rel(sd1[k[4:]].cpu().numpy(), g8[k]) < 1e-4, k

@@ -127,7 +127,8 @@ int ws_transpose_build(const int64_t* inds, int64_t nq, int32_t h, int64_t ns, i
         WS_HIP(hipMemcpyAsync(cursor, t_offsets, sizeof(int32_t) * (ns + 2), hipMemcpyDeviceToDevice, st));
         tr_fill<<<ws_grid(np, 256), 256, 0, st>>>(inds, np, ns, cursor, t_pairs);
         WS_LAUNCH_CHECK();
-        tr_sort_lists<<<ws_grid(nlists, 4), 256, 0, st>>>(t_offsets, nlists, t_pairs);
+        // the shadow list (slot ns) is never read by a backward kernel: not sorted
+        tr_sort_lists<<<ws_grid(ns, 4), 256, 0, st>>>(t_offsets, ns, t_pairs);
         WS_LAUNCH_CHECK();
     }
     return WS_OK;

@@ -13,6 +13,25 @@ import torch
 from . import _lib
 from ._lib import check, current_stream, ptr
 
+# optional launch timer (bench.py): an object with begin(key) -> token / end(token); records HIP
+# events on the current stream around selected kernel launches.  None = no overhead.
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _tbegin(*key):
+    return _timer.begin(key) if _timer is not None else None
+
+
+def _tend(tok):
+    if tok is not None:
+        _timer.end(tok)
+
+
 INFLUENCE = {"linear": 0, "constant": 1, "gaussian": 2}
 AGGREGATION = {"sum": 0, "closest": 1}
 
@@ -92,9 +111,11 @@ class _KPConvGather(torch.autograd.Function):
         min_d2 = torch.empty((nq, k), dtype=torch.float32, device=x.device) if want_min_d2 else None
         dkp = deformed_kp.contiguous() if deformed_kp is not None else None
         mod = modulations.contiguous() if modulations is not None else None
+        tok = _tbegin("kpconv_gather_fwd", nq, h, ci)
         check(lib.ws_kpconv_gather_fwd(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci,
                                        ptr(kernel_points), k, ptr(dkp), ptr(mod), float(extent),
                                        influence, aggregation, ptr(wf), ptr(min_d2), current_stream()))
+        _tend(tok)
         ctx.save_for_backward(x, dkp, mod, q_pts, s_pts, inds, kernel_points)
         ctx.cfg = (float(extent), influence, aggregation)
         return wf, min_d2
@@ -112,9 +133,11 @@ class _KPConvGather(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             table = transposed_table(inds, ns)
             dx = torch.empty_like(x)
+            tok = _tbegin("kpconv_gather_bwd_x", nq, h, ci)
             check(lib.ws_kpconv_gather_bwd_x(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(table.offsets),
                                              ptr(table.pairs), ptr(dwf), ci, ptr(kernel_points), k, ptr(dkp),
                                              ptr(mod), extent, influence, aggregation, ptr(dx), current_stream()))
+            _tend(tok)
         if dkp is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             d_dkp = torch.empty_like(dkp)
             d_mod = torch.empty_like(mod) if mod is not None else None

@@ -1,0 +1,133 @@
+"""Input pyramid of the KP-FCNN on the GPU.
+
+The reference builds the multi-scale inputs on the CPU inside DataLoader workers
+(datasets/common.py:461-577 ``PointCloudDataset.segmentation_inputs``): per layer one
+``batch_neighbors`` for the convolution, one ``batch_grid_subsampling`` and two more
+``batch_neighbors`` for pooling / upsampling, with the neighbour matrices cropped to the calibrated
+``neighborhood_limits`` and cast to int64.  Here the same schedule (radii, cell sizes, crop, list
+layout, dtypes) runs on device tensors with the HIP geometry kernels; nothing goes back to the host
+except the per-call row widths / lengths.
+
+``batch_grid_subsampling`` reproduces the reference's random grid orientation
+(common.py:77-135, ``random_grid_orient=True`` by default): the rotation matrices are drawn from
+``np.random`` on the host in the reference's order (theta, phi, alpha per call), the rotations are
+applied on the device with the reference's f32 summation order.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .kernel_points import create_3D_rotations
+
+
+def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None):
+    """device form of datasets/common.py:185-196 (+ the crop of :336-346 and the int64 cast of :551)"""
+    return ops.radius_neighbors(queries, supports, q_batches, s_batches, radius, limit=limit, dtype=torch.int64)
+
+
+def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_grid_orient=True):
+    """device form of datasets/common.py:77-182 (points only, the form the pyramid uses :521)"""
+    lens = np.asarray(batches_len, dtype=np.int32)
+    B = len(lens)
+    if not random_grid_orient:
+        return ops.grid_subsample(points, lens, sampleDl, max_p=max_p)
+    theta = np.random.rand(B) * 2 * np.pi
+    phi = (np.random.rand(B) - 0.5) * np.pi
+    u = np.vstack([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
+    alpha = np.random.rand(B) * 2 * np.pi
+    R = create_3D_rotations(u.T, alpha).astype(np.float32)
+    R_dev = torch.from_numpy(R).to(points.device)
+    lens_dev = torch.from_numpy(lens).to(points.device)
+    rotated = ops.rotate_clouds(points, lens_dev, R_dev)
+    s_points, s_len = ops.grid_subsample(rotated, lens, sampleDl, max_p=max_p)
+    s_len_dev = torch.from_numpy(s_len).to(points.device)
+    s_points = ops.rotate_clouds(s_points, s_len_dev, R_dev, transpose=True)
+    return s_points, s_len
+
+
+def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_lengths,
+                        neighborhood_limits=(), random_grid_orient=True):
+    """-> flat list  points[L] + neighbors[L] + pools[L] + upsamples[L] + lengths[L] + [features, labels]
+    (datasets/common.py:574-575), all device tensors (lengths int32, indices int64)."""
+    dev = stacked_points.device
+    lens = np.asarray(stack_lengths.cpu() if isinstance(stack_lengths, torch.Tensor) else stack_lengths, dtype=np.int32)
+    r_normal = config.first_subsampling_dl * config.conv_radius
+    limits = list(neighborhood_limits)
+
+    def limit(layer):
+        return limits[layer] if len(limits) > 0 else None
+
+    layer_blocks = []
+    input_points, input_neighbors, input_pools, input_upsamples, input_lengths = [], [], [], [], []
+    empty_i = lambda: torch.zeros((0, 1), dtype=torch.int64, device=dev)
+    for block in config.architecture:
+        if not any(tag in block for tag in ('pool', 'strided', 'global', 'upsample')):
+            layer_blocks.append(block)
+            continue
+        layer = len(input_points)
+        if layer_blocks:
+            if any('deformable' in b for b in layer_blocks):
+                r = r_normal * config.deform_radius / config.conv_radius
+            else:
+                r = r_normal
+            conv_i = batch_neighbors(stacked_points, stacked_points, lens, lens, r, limit(layer))
+        else:
+            conv_i = empty_i()
+        if 'pool' in block or 'strided' in block:
+            dl = 2 * r_normal / config.conv_radius
+            pool_p, pool_b = batch_grid_subsampling(stacked_points, lens, sampleDl=dl,
+                                                    random_grid_orient=random_grid_orient)
+            r = r_normal * config.deform_radius / config.conv_radius if 'deformable' in block else r_normal
+            pool_i = batch_neighbors(pool_p, stacked_points, pool_b, lens, r, limit(layer))
+            up_i = batch_neighbors(stacked_points, pool_p, lens, pool_b, 2 * r, limit(layer + 1))
+        else:
+            pool_i = empty_i()
+            pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+            pool_b = np.zeros((0,), dtype=np.int32)
+            up_i = empty_i()
+        input_points.append(stacked_points)
+        input_neighbors.append(conv_i)
+        input_pools.append(pool_i)
+        input_upsamples.append(up_i)
+        input_lengths.append(torch.from_numpy(np.ascontiguousarray(lens)).to(dev))
+        stacked_points, lens = pool_p, pool_b
+        r_normal *= 2
+        layer_blocks = []
+        if 'global' in block or 'upsample' in block:
+            break
+    return (input_points + input_neighbors + input_pools + input_upsamples + input_lengths
+            + [stacked_features, labels])
+
+
+class PyramidBatch:
+    """The `batch` object the blocks index (``.points/.neighbors/.pools/.upsamples/.lengths/
+    .features/.labels``), built from the flat list like the reference's CustomBatch classes
+    (datasets/DALES_PseudoLabel.py:1386-1460)."""
+
+    def __init__(self, input_list):
+        L = (len(input_list) - 2) // 5
+        self.points = list(input_list[0:L])
+        self.neighbors = list(input_list[L:2 * L])
+        self.pools = list(input_list[2 * L:3 * L])
+        self.upsamples = list(input_list[3 * L:4 * L])
+        self.lengths = list(input_list[4 * L:5 * L])
+        self.features = input_list[5 * L]
+        self.labels = input_list[5 * L + 1]
+
+    def _map(self, fn):
+        for name in ("points", "neighbors", "pools", "upsamples", "lengths"):
+            setattr(self, name, [fn(t) for t in getattr(self, name)])
+        self.features = fn(self.features)
+        self.labels = fn(self.labels)
+        return self
+
+    def to(self, device):
+        return self._map(lambda t: t.to(device))
+
+    def pin_memory(self):
+        return self._map(lambda t: t.pin_memory())
+
+
+def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True):
+    return PyramidBatch(segmentation_inputs(config, points, features, labels, lengths, neighborhood_limits,
+                                            random_grid_orient))

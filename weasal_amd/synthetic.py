@@ -1,0 +1,38 @@
+"""Synthetic sphere batches: N points i.i.d. uniform in a ball, labels
+uniform in [0, 9), features [1, z, z] (DALES, in_features_dim 3) or [1, U(0,1), z, z]
+(Vaihingen3D, in_features_dim 4)."""
+import numpy as np
+
+# BASELINE.json configs (C2 = Vaihingen-PL, C3 = DALES-PL); neighbour limits are the 90th
+# percentiles measured in the survey on this distribution
+WORKLOADS = {
+    "dales": dict(config="DALESPLConfig", radius=10.0, points=50000, spheres=8, limits=[59, 73, 81, 77, 56],
+                  name="DALES_PseudoLabel KP-FCNN, in_radius=10m, 50k pts/sphere, batch=8"),
+    "vaihingen": dict(config="Vaihingen3DPLConfig", radius=4.0, points=3000, spheres=4, limits=[],
+                      name="Vaihingen3D_PseudoLabel KP-FCNN, in_radius=4m, 3k pts/sphere, batch=4"),
+}
+
+
+def sphere(rng, n, R):
+    pts = np.zeros((0, 3), np.float32)
+    while len(pts) < n:
+        c = rng.uniform(-R, R, size=(int(2.2 * n), 3)).astype(np.float32)
+        pts = np.concatenate([pts, c[(c.astype(np.float64) ** 2).sum(1) < R * R]])
+    return pts[:n]
+
+
+def make_inputs(seed, spheres, points, radius, in_features_dim, num_classes=9):
+    """-> (points [B*n,3] f32, features [B*n,d] f32, labels [B*n] int64, lengths [B] int32)"""
+    rng = np.random.default_rng(seed)
+    pts = np.concatenate([sphere(rng, points, radius) for _ in range(spheres)]).astype(np.float32)
+    n = pts.shape[0]
+    z = pts[:, 2:3]
+    if in_features_dim == 3:
+        feats = np.concatenate([np.ones((n, 1), np.float32), z, z], axis=1)
+    elif in_features_dim == 4:
+        feats = np.concatenate([np.ones((n, 1), np.float32), rng.random((n, 1)).astype(np.float32), z, z], axis=1)
+    else:
+        feats = np.ones((n, in_features_dim), np.float32)
+    labels = rng.integers(0, num_classes, size=n).astype(np.int64)
+    lens = np.full(spheres, points, np.int32)
+    return pts, feats.astype(np.float32), labels, lens
