@@ -100,7 +100,8 @@ int ws_kpconv_gather_bwd_geom(const float* q_pts, int64_t nq, const float* s_pts
 /* Transposed neighbour table (support -> list of flat pair ids q*h+col), the deterministic
  * replacement of the scatter_add in the autograd of blocks.gather (blocks.py:36-67).
  * t_offsets [ns+2] int32: entries of support s are t_pairs[t_offsets[s] .. t_offsets[s+1]);
- * slot ns collects the shadow pairs.  Lists are sorted by pair id.  Requires nq*h < 2^31.
+ * shadow pairs (index == ns) are not tabulated (slot ns stays empty).  Lists are sorted by pair id.
+ * Requires nq*h < 2^31.
  * scratch: at least ws_transpose_scratch_bytes(nq,h,ns) bytes. */
 int64_t ws_transpose_scratch_bytes(int64_t nq, int32_t h, int64_t ns);
 int ws_transpose_build(const int64_t* inds, int64_t nq, int32_t h, int64_t ns,

@@ -14,8 +14,8 @@ __global__ __launch_bounds__(256) void tr_count(const int64_t* __restrict__ inds
                                                  int32_t* __restrict__ counts)
 {
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < np; p += (int64_t)gridDim.x * 256) {
-        int64_t s = inds[p];
-        if (s < 0 || s > ns) s = ns;
+        const int64_t s = inds[p];
+        if (s < 0 || s >= ns) continue;     // shadow pairs carry no gradient: not tabulated
         atomicAdd(&counts[s], 1);
     }
 }
@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void tr_fill(const int64_t* __restrict__ inds,
                                                 int32_t* __restrict__ cursor, int32_t* __restrict__ pairs)
 {
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < np; p += (int64_t)gridDim.x * 256) {
-        int64_t s = inds[p];
-        if (s < 0 || s > ns) s = ns;
+        const int64_t s = inds[p];
+        if (s < 0 || s >= ns) continue;
         const int pos = atomicAdd(&cursor[s], 1);
         pairs[pos] = (int32_t)p;
     }
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void tr_sort_lists(const int32_t* __restrict__
                                                       int32_t* __restrict__ pairs)
 {
     __shared__ int32_t slab_all[4][SORT_CAP];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int32_t* slab = slab_all[wave];
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < nlists; s += (int64_t)gridDim.x * 4) {
         const int beg = offsets[s], end = offsets[s + 1];

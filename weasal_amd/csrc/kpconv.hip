@@ -73,9 +73,60 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 forward, ci >= 5.  CC = channel chunk (16 or 32), ES = 64/CC entry slots.
+// Pool + accumulate structure shared by K3 (forward) and K4 (backward w.r.t. x).
+//
+// One wave owns one query (K3) / one support (K4) at a time and works in two alternating phases:
+//   list phase   lane = neighbour column (K3) or incoming pair (K4).  For each kernel point the
+//                influence is evaluated in registers (nothing is kept per kernel point), the
+//                non-zero ones are compacted by ballot + mbcnt into the wave's LDS entry pool as
+//                (row | k, weight).  With `linear` influence ~1 of the 15 kernel points is
+//                non-zero per neighbour, so the pool holds ~H entries instead of 15*H.
+//   flush phase  lane = (entry slot, 16-byte piece of the row): G lanes read one feature row
+//                segment as float4 (a row is 4*ci contiguous bytes -> 64..256-byte coalesced
+//                segments straight from L2/HBM, no staging copy), S = 64/G entries per step.
+//                K3 adds w * x into the wave's LDS accumulator wf[k][c] (ds_add_f32, order fixed
+//                by lane and instruction order -> deterministic); K4 adds into registers.
+// The pool is flushed whenever it could overflow, so any H / any influence mode fits.
 // ---------------------------------------------------------------------------------------------
-template <int K, int CC>
+constexpr int POOL = 320;   // entries per wave (8 B each); must be >= 128
+
+__device__ __forceinline__ int lane_rank(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// influence of ONE kernel point (same formulas as kp_influence)
+__device__ __forceinline__ float kp_weight(float d2, const GeomParams& g, float inv_extent)
+{
+    if (g.influence == WS_INFLUENCE_LINEAR) return fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.0f);
+    if (g.influence == WS_INFLUENCE_CONSTANT) return 1.0f;
+    const float sig = g.extent * 0.3f;
+    return __expf(-d2 / (2.0f * sig * sig + 1e-9f));
+}
+
+__device__ __forceinline__ float kp_d2(float nx, float ny, float nz, const float* __restrict__ kp, int k)
+{
+    const float dx = nx - kp[3 * k + 0], dy = ny - kp[3 * k + 1], dz = nz - kp[3 * k + 2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+template <int G>
+__device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base, int64_t row, int ci, int ch, int vec4)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = base + row * ci + ch;
+    if (vec4 && ch + 3 < ci) {
+        v = *reinterpret_cast<const float4*>(src);
+    } else {
+        if (ch + 0 < ci) v.x = src[0];
+        if (ch + 1 < ci) v.y = src[1];
+        if (ch + 2 < ci) v.z = src[2];
+        if (ch + 3 < ci) v.w = src[3];
+    }
+    return v;
+}
+
+template <int K, int G>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
@@ -83,15 +134,54 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float* __restrict__ modulations, GeomParams g, float* __restrict__ wf,
     float* __restrict__ min_d2, int vec4)
 {
-    constexpr int ES = 64 / CC;
-    constexpr int PIECES = CC / 4;            // 16-byte pieces per staged row
-    constexpr int ROWS_PER_I = 64 / PIECES;   // rows staged per wave-instruction
-    __shared__ __attribute__((aligned(16))) float slab_all[4][64 * CC];
-    const int wave = threadIdx.x >> 6;
+    constexpr int CC = 4 * G;      // channels per chunk
+    constexpr int S = 64 / G;      // entry slots
+    __shared__ uint2 pool_all[4][POOL];
+    __shared__ __attribute__((aligned(16))) float acc_all[4][K * CC];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    float* slab = slab_all[wave];
-    const int c = lane % CC;       // channel inside the chunk
-    const int slot = lane / CC;    // entry slot
+    uint2* pool = pool_all[wave];
+    float* acc = acc_all[wave];
+    const int j = lane % G;        // 16-byte piece of the row chunk
+    const int slot = lane / G;
+    const float inv_extent = 1.0f / g.extent;
+    const float e2 = g.extent * g.extent;
+    const bool need_pre = g.deformable || g.aggregation == WS_AGGREGATION_CLOSEST;
+
+    for (int i = lane; i < K * CC; i += 64) acc[i] = 0.0f;
+    wave_lds_sync();
+
+    // accumulate pool[0..total) into acc for channel chunk cc0
+    auto flush = [&](int total, int cc0) {
+        wave_lds_sync();
+        const int per = (total + S - 1) / S;
+        const int ch = cc0 + 4 * j;
+        for (int it = 0; it < per; it += 2) {
+            uint2 e[2];
+            float4 v[2];
+            bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = slot * per + it + u;
+                ok[u] = (it + u) < per && idx < total;
+                e[u] = ok[u] ? pool[idx] : make_uint2(0u, 0u);
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[u]) v[u] = load_row_piece<G>(x, (int64_t)(e[u].x >> 4), ci, ch, vec4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (ok[u]) {
+                    const float w = __uint_as_float(e[u].y);
+                    float* a = acc + (e[u].x & 15u) * CC + 4 * j;
+                    atomicAdd(a + 0, w * v[u].x);
+                    atomicAdd(a + 1, w * v[u].y);
+                    atomicAdd(a + 2, w * v[u].z);
+                    atomicAdd(a + 3, w * v[u].w);
+                }
+            }
+        }
+        wave_lds_sync();
+    };
 
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
         const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
@@ -102,80 +192,61 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
             for (int k = 0; k < K; ++k) mind[k] = 3.4e38f;
         }
         for (int cc0 = 0; cc0 < ci; cc0 += CC) {
-            float acc[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+            int total = 0;
             for (int h0 = 0; h0 < h; h0 += 64) {
-                // ---- phase 1: lane = neighbour column
                 const int col = h0 + lane;
                 const bool incol = col < h;
-                int64_t idx = incol ? inds[q * h + col] : ns;
+                const int64_t idx = incol ? inds[q * h + col] : ns;
                 const bool real = incol && idx < ns && idx >= 0;
-                float px = WS_SHADOW, py = WS_SHADOW, pz = WS_SHADOW;
-                if (real) { px = s_pts[3 * idx]; py = s_pts[3 * idx + 1]; pz = s_pts[3 * idx + 2]; }
-                float w[K], d2[K];
-                kp_influence<K>(px - qx, py - qy, pz - qz, kp, g, real, w, d2);
-                if (min_d2 && cc0 == 0) {
+                float nx = WS_SHADOW - qx, ny = WS_SHADOW - qy, nz = WS_SHADOW - qz;
+                if (real) { nx = s_pts[3 * idx] - qx; ny = s_pts[3 * idx + 1] - qy; nz = s_pts[3 * idx + 2] - qz; }
+                bool live = real;
+                int arg = 0;
+                if (need_pre) {
+                    float best = 3.4e38f;
+                    bool inrange = false;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) if (incol) mind[k] = fminf(mind[k], d2[k]);
-                }
-                bool any = false;
-#pragma unroll
-                for (int k = 0; k < K; ++k) any |= w[k] != 0.0f;
-                const int idx32 = real ? (int)idx : 0;
-                // ---- phase 2: stage rows [64][CC] (only rows with some influence)
-#pragma unroll
-                for (int r0 = 0; r0 < 64; r0 += ROWS_PER_I) {
-                    const int r = r0 + lane / PIECES;
-                    const int j = lane % PIECES;
-                    const int ridx = __shfl(idx32, r, 64);
-                    const int need = __shfl((int)any, r, 64);
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int ch = cc0 + 4 * j;
-                    if (need) {
-                        const float* src = x + (int64_t)ridx * ci + ch;
-                        if (vec4 && ch + 3 < ci) {
-                            v = *reinterpret_cast<const float4*>(src);
-                        } else {
-                            if (ch + 0 < ci) v.x = src[0];
-                            if (ch + 1 < ci) v.y = src[1];
-                            if (ch + 2 < ci) v.z = src[2];
-                            if (ch + 3 < ci) v.w = src[3];
-                        }
+                    for (int k = 0; k < K; ++k) {
+                        const float d = kp_d2(nx, ny, nz, kp, k);
+                        if (d < best) { best = d; arg = k; }
+                        inrange |= d < e2;
                     }
-                    *reinterpret_cast<float4*>(&slab[r * CC + 4 * j]) = v;
+                    if (g.deformable) live = live && inrange;
                 }
-                wave_lds_sync();
-                // ---- phase 3: lane = (slot, channel); sparse accumulate per kernel point
+                const unsigned tag = (unsigned)(real ? (int)idx : 0) << 4;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    unsigned long long m = __ballot(w[k] != 0.0f);
-                    while (m) {
-                        int hh = 0;
-                        float ww = 0.0f;
-#pragma unroll
-                        for (int e = 0; e < ES; ++e) {
-                            if (m) {
-                                const int hb = __builtin_ctzll(m);
-                                m &= m - 1;
-                                const float wb = ws_readlane_f(w[k], hb);
-                                if (slot == e) { hh = hb; ww = wb; }
-                            }
-                        }
-                        acc[k] = fmaf(ww, slab[hh * CC + c], acc[k]);
-                    }
+                    const float d = kp_d2(nx, ny, nz, kp, k);
+                    if (min_d2 && cc0 == 0 && incol) mind[k] = fminf(mind[k], d);
+                    float w = kp_weight(d, g, inv_extent);
+                    if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
+                    if (!live) w = 0.0f;
+                    const bool nzw = w != 0.0f;
+                    const unsigned long long m = __ballot(nzw);
+                    if (total + 64 > POOL) { flush(total, cc0); total = 0; }
+                    if (nzw) pool[total + lane_rank(m)] = make_uint2(tag | (unsigned)k, __float_as_uint(w));
+                    total += __builtin_popcountll(m);
                 }
-                wave_lds_sync();
             }
-            // ---- combine entry slots and write wf[q, k, cc0 + c]
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float a = acc[k];
-#pragma unroll
-                for (int o = CC; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-                if (modulations) a *= modulations[q * K + k];
-                if (slot == 0 && cc0 + c < ci) wf[(q * K + k) * ci + cc0 + c] = a;
+            flush(total, cc0);
+            // write wf[q, k, cc0 .. cc0+CC) and clear the accumulator
+            for (int i = lane; i < K * G; i += 64) {
+                const int k = i / G, jj = i - k * G;
+                float4 v = *reinterpret_cast<float4*>(&acc[k * CC + 4 * jj]);
+                *reinterpret_cast<float4*>(&acc[k * CC + 4 * jj]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (modulations) { const float md = modulations[q * K + k]; v.x *= md; v.y *= md; v.z *= md; v.w *= md; }
+                const int ch = cc0 + 4 * jj;
+                float* dst = wf + (q * K + k) * ci + ch;
+                if (vec4 && ch + 3 < ci) {
+                    *reinterpret_cast<float4*>(dst) = v;
+                } else {
+                    if (ch + 0 < ci) dst[0] = v.x;
+                    if (ch + 1 < ci) dst[1] = v.y;
+                    if (ch + 2 < ci) dst[2] = v.z;
+                    if (ch + 3 < ci) dst[3] = v.w;
+                }
             }
+            wave_lds_sync();
         }
         if (min_d2) {
 #pragma unroll
@@ -190,157 +261,116 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 forward, ci <= 4 (input layer: in_features_dim 1..4).  lane = neighbour column holds its own
-// feature row in registers; wf[q,k,c] is a wave reduction.  No LDS.
+// K4 backward w.r.t. x through the transposed table: dx[s, :] = sum_e weight_e * dwf[row_e, :]
 // ---------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(256) void kpconv_gather_fwd_small_kernel(
-    const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
-    const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
-    const float* __restrict__ kernel_points, const float* __restrict__ deformed_kp,
-    const float* __restrict__ modulations, GeomParams g, float* __restrict__ wf,
-    float* __restrict__ min_d2)
-{
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
-        const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
-        const float* kp = deformed_kp ? deformed_kp + q * (3 * K) : kernel_points;
-        float acc[K][4];
-        float mind[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            mind[k] = 3.4e38f;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) acc[k][cc] = 0.0f;
-        }
-        for (int h0 = 0; h0 < h; h0 += 64) {
-            const int col = h0 + lane;
-            const bool incol = col < h;
-            int64_t idx = incol ? inds[q * h + col] : ns;
-            const bool real = incol && idx < ns && idx >= 0;
-            float px = WS_SHADOW, py = WS_SHADOW, pz = WS_SHADOW;
-            float xv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (real) {
-                px = s_pts[3 * idx]; py = s_pts[3 * idx + 1]; pz = s_pts[3 * idx + 2];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) if (cc < ci) xv[cc] = x[idx * ci + cc];
-            }
-            float w[K], d2[K];
-            kp_influence<K>(px - qx, py - qy, pz - qz, kp, g, real, w, d2);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (incol) mind[k] = fminf(mind[k], d2[k]);
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) acc[k][cc] = fmaf(w[k], xv[cc], acc[k][cc]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float mod = modulations ? modulations[q * K + k] : 1.0f;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                if (cc < ci) {
-                    const float a = ws_wave_sum(acc[k][cc]);
-                    if (lane == 0) wf[(q * K + k) * ci + cc] = a * mod;
-                }
-            }
-            if (min_d2) {
-                float m = mind[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-                if (lane == 0) min_d2[q * K + k] = m;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4 backward w.r.t. x through the transposed table.  One wave per support point s:
-//   phase 1: lane = incoming pair (q,col): influence of the K kernel points (recomputed);
-//            non-zero (row = q*K+k, weight) entries are compacted into the wave's LDS list;
-//   phase 2: lane = (slot, channel): dx[s, c] = sum_e weight_e * dwf[row_e, c], rows read straight
-//            from HBM/L2 (each row is 4*ci contiguous bytes), UNROLL entries in flight per slot.
-// ---------------------------------------------------------------------------------------------
-template <int K, int CC>
+template <int K, int G>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     int h, const int32_t* __restrict__ t_offsets, const int32_t* __restrict__ t_pairs,
     const float* __restrict__ dwf, int ci, const float* __restrict__ kernel_points,
     const float* __restrict__ deformed_kp, const float* __restrict__ modulations, GeomParams g,
-    float* __restrict__ dx)
+    float* __restrict__ dx, int vec4)
 {
-    constexpr int ES = 64 / CC;
-    constexpr int LIST = 64 * K;   // worst case: every pair touches every kernel point
-    __shared__ int l_row_all[4][LIST];
-    __shared__ float l_w_all[4][LIST];
-    const int wave = threadIdx.x >> 6;
+    constexpr int CC = 4 * G;
+    constexpr int S = 64 / G;
+    __shared__ uint2 pool_all[4][POOL];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    int* l_row = l_row_all[wave];
-    float* l_w = l_w_all[wave];
-    const int c = lane % CC;
-    const int slot = lane / CC;
+    uint2* pool = pool_all[wave];
+    const int j = lane % G;
+    const int slot = lane / G;
+    const float inv_extent = 1.0f / g.extent;
+    const float e2 = g.extent * g.extent;
+    const bool need_pre = g.deformable || g.aggregation == WS_AGGREGATION_CLOSEST;
 
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < ns; s += (int64_t)gridDim.x * 4) {
         const float sx = s_pts[3 * s + 0], sy = s_pts[3 * s + 1], sz = s_pts[3 * s + 2];
         const int beg = t_offsets[s], end = t_offsets[s + 1];
         for (int cc0 = 0; cc0 < ci; cc0 += CC) {
-            float acc = 0.0f;
-            for (int p0 = beg; p0 < end; p0 += 64) {
-                // ---- phase 1
-                const int p = p0 + lane;
-                const bool live = p < end;
-                const int pair = live ? t_pairs[p] : 0;
-                const int q = pair / h;
-                float w[K], d2[K];
-                {
-                    const float nx = sx - q_pts[3 * (int64_t)q + 0];
-                    const float ny = sy - q_pts[3 * (int64_t)q + 1];
-                    const float nz = sz - q_pts[3 * (int64_t)q + 2];
-                    if (deformed_kp) {
-                        // per-lane kernel points (not wave-uniform here)
-                        float kpl[3 * K];
-#pragma unroll
-                        for (int t = 0; t < 3 * K; ++t) kpl[t] = deformed_kp[(int64_t)q * (3 * K) + t];
-                        kp_influence<K>(nx, ny, nz, kpl, g, live, w, d2);
-                    } else {
-                        kp_influence<K>(nx, ny, nz, kernel_points, g, live, w, d2);
-                    }
-                }
-                int total = 0;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    float wk = w[k];
-                    if (modulations && wk != 0.0f) wk *= modulations[(int64_t)q * K + k];
-                    const bool nz_ = wk != 0.0f;
-                    const unsigned long long m = __ballot(nz_);
-                    if (nz_) {
-                        const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                        l_row[total + rank] = q * K + k;
-                        l_w[total + rank] = wk;
-                    }
-                    total += __builtin_popcountll(m);
-                }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ch = cc0 + 4 * j;
+            auto flush = [&](int total) {
                 wave_lds_sync();
-                // ---- phase 2
-                for (int e0 = 0; e0 < total; e0 += ES * 4) {
-                    float xv[4], wv[4];
+                const int per = (total + S - 1) / S;
+                for (int it = 0; it < per; it += 4) {
+                    float4 v[4];
+                    float w[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int e = e0 + u * ES + slot;
-                        const bool ok = e < total && (cc0 + c) < ci;
-                        const int row = ok ? l_row[e] : 0;
-                        wv[u] = ok ? l_w[e] : 0.0f;
-                        xv[u] = ok ? dwf[(int64_t)row * ci + cc0 + c] : 0.0f;
+                        const int idx = slot * per + it + u;
+                        const bool ok = (it + u) < per && idx < total;
+                        const uint2 e = ok ? pool[idx] : make_uint2(0u, 0u);
+                        w[u] = ok ? __uint_as_float(e.y) : 0.0f;
+                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok) v[u] = load_row_piece<G>(dwf, (int64_t)e.x, ci, ch, vec4);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc = fmaf(wv[u], xv[u], acc);
+                    for (int u = 0; u < 4; ++u) {
+                        acc.x = fmaf(w[u], v[u].x, acc.x);
+                        acc.y = fmaf(w[u], v[u].y, acc.y);
+                        acc.z = fmaf(w[u], v[u].z, acc.z);
+                        acc.w = fmaf(w[u], v[u].w, acc.w);
+                    }
                 }
                 wave_lds_sync();
-            }
+            };
+            int total = 0;
+            for (int p0 = beg; p0 < end; p0 += 64) {
+                const int p = p0 + lane;
+                const bool real = p < end;
+                const int pair = real ? t_pairs[p] : 0;
+                const int q = pair / h;
+                const float nx = sx - q_pts[3 * (int64_t)q + 0];
+                const float ny = sy - q_pts[3 * (int64_t)q + 1];
+                const float nz = sz - q_pts[3 * (int64_t)q + 2];
+                const float* kp = deformed_kp ? deformed_kp + (int64_t)q * (3 * K) : kernel_points;   // per lane if deformed
+                bool live = real;
+                int arg = 0;
+                if (need_pre) {
+                    float best = 3.4e38f;
+                    bool inrange = false;
 #pragma unroll
-            for (int o = CC; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
-            if (slot == 0 && cc0 + c < ci) dx[s * ci + cc0 + c] = acc;
+                    for (int k = 0; k < K; ++k) {
+                        const float d = kp_d2(nx, ny, nz, kp, k);
+                        if (d < best) { best = d; arg = k; }
+                        inrange |= d < e2;
+                    }
+                    if (g.deformable) live = live && inrange;
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float d = kp_d2(nx, ny, nz, kp, k);
+                    float w = kp_weight(d, g, inv_extent);
+                    if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
+                    if (!live) w = 0.0f;
+                    if (modulations && w != 0.0f) w *= modulations[(int64_t)q * K + k];
+                    const bool nzw = w != 0.0f;
+                    const unsigned long long m = __ballot(nzw);
+                    if (total + 64 > POOL) { flush(total); total = 0; }
+                    if (nzw) pool[total + lane_rank(m)] = make_uint2((unsigned)(q * K + k), __float_as_uint(w));
+                    total += __builtin_popcountll(m);
+                }
+            }
+            flush(total);
+            // sum the S slots
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o, 64);
+                acc.y += __shfl_xor(acc.y, o, 64);
+                acc.z += __shfl_xor(acc.z, o, 64);
+                acc.w += __shfl_xor(acc.w, o, 64);
+            }
+            if (slot == 0) {
+                float* dst = dx + s * ci + ch;
+                if (vec4 && ch + 3 < ci) {
+                    *reinterpret_cast<float4*>(dst) = acc;
+                } else {
+                    if (ch + 0 < ci) dst[0] = acc.x;
+                    if (ch + 1 < ci) dst[1] = acc.y;
+                    if (ch + 2 < ci) dst[2] = acc.z;
+                    if (ch + 3 < ci) dst[3] = acc.w;
+                }
+            }
         }
     }
 }
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_kernel(
     const float* __restrict__ modulations, const float* __restrict__ d_min_d2, GeomParams g,
     float* __restrict__ d_kp, float* __restrict__ d_mod)
 {
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
         const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
@@ -488,18 +518,17 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
     GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(nq, 4);
-    if (ci <= 4) {
-        kpconv_gather_fwd_small_kernel<15><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points,
-                                                                 deformed_kp, modulations, g, wf, min_d2);
-    } else {
-        const int vec4 = (ci % 4 == 0) && aligned16(x);
-        if (ci <= 16)
-            kpconv_gather_fwd_kernel<15, 16><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points,
-                                                                   deformed_kp, modulations, g, wf, min_d2, vec4);
-        else
-            kpconv_gather_fwd_kernel<15, 32><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points,
-                                                                   deformed_kp, modulations, g, wf, min_d2, vec4);
-    }
+    WS_REQUIRE(ns < (1ll << 27), "ns exceeds the 2^27 rows the entry pool can tag");
+    const int vec4 = (ci % 4 == 0) && aligned16(x) && aligned16(wf);
+#define WS_FWD(G)                                                                                              \
+    kpconv_gather_fwd_kernel<15, G><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points, \
+                                                          deformed_kp, modulations, g, wf, min_d2, vec4)
+    if (ci <= 4) WS_FWD(1);
+    else if (ci <= 8) WS_FWD(2);
+    else if (ci <= 16) WS_FWD(4);
+    else if (ci <= 32) WS_FWD(8);
+    else WS_FWD(16);
+#undef WS_FWD
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
@@ -519,12 +548,16 @@ int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, i
     GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(ns, 4);
-    if (ci <= 16)
-        kpconv_gather_bwd_x_kernel<15, 16><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, dwf, ci,
-                                                                 kernel_points, deformed_kp, modulations, g, dx);
-    else
-        kpconv_gather_bwd_x_kernel<15, 32><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, dwf, ci,
-                                                                 kernel_points, deformed_kp, modulations, g, dx);
+    const int vec4 = (ci % 4 == 0) && aligned16(dwf) && aligned16(dx);
+#define WS_BWD(G)                                                                                               \
+    kpconv_gather_bwd_x_kernel<15, G><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, dwf, ci, \
+                                                            kernel_points, deformed_kp, modulations, g, dx, vec4)
+    if (ci <= 4) WS_BWD(1);
+    else if (ci <= 8) WS_BWD(2);
+    else if (ci <= 16) WS_BWD(4);
+    else if (ci <= 32) WS_BWD(8);
+    else WS_BWD(16);
+#undef WS_BWD
     WS_LAUNCH_CHECK();
     return WS_OK;
 }

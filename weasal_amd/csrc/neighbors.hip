@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void nb_count_kernel(const float* __restrict__
                                                         const float4* __restrict__ sorted, float r2,
                                                         int32_t* __restrict__ counts, int32_t* __restrict__ max_count)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int local_max = 0;
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
         const int b = find_cloud_q(grids, nb, q);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
                                                        int width, OutT* __restrict__ out)
 {
     __shared__ unsigned long long slab_all[4][CAP];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned long long* slab = slab_all[wave];
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
         const int b = find_cloud_q(grids, nb, q);

@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float* __restri
                                                             const int64_t* __restrict__ inds, int64_t nq, int h,
                                                             float* __restrict__ out, int32_t* __restrict__ arg)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
         for (int c0 = 0; c0 < c; c0 += 64) {
             const int ch = c0 + lane;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float* __restri
                                                             const int32_t* __restrict__ t_pairs, int64_t ns,
                                                             float* __restrict__ dx)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < ns; s += (int64_t)gridDim.x * 4) {
         const int beg = t_offsets[s], end = t_offsets[s + 1];
         for (int c0 = 0; c0 < c; c0 += 64) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void closest_pool_fwd_kernel(const float* __re
                                                                 const int64_t* __restrict__ inds, int64_t nq, int h,
                                                                 float* __restrict__ out)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
         const int64_t s = inds[q * h];
         const bool real = s >= 0 && s < ns;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void closest_pool_bwd_kernel(const float* __re
                                                                 const int32_t* __restrict__ t_pairs, int64_t ns,
                                                                 float* __restrict__ dx)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < ns; s += (int64_t)gridDim.x * 4) {
         const int beg = t_offsets[s], end = t_offsets[s + 1];
         for (int c0 = 0; c0 < c; c0 += 64) {

@@ -203,20 +203,22 @@ class _ClosestPool(torch.autograd.Function):
         nq, h = inds.shape
         out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
         check(lib.ws_closest_pool_fwd(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), current_stream()))
-        ctx.save_for_backward(inds)
+        # only the first column takes part (blocks.py:92): the backward needs the transposed
+        # table of that column alone (lists of ~N_fine/N_coarse entries instead of ~H times that)
+        ctx.col0 = inds[:, :1].contiguous()
         ctx.ns = ns
         return out
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.lib()
-        (inds,) = ctx.saved_tensors
-        nq, h = inds.shape
+        col0 = ctx.col0
+        nq = col0.shape[0]
         c = dy.shape[1]
-        table = transposed_table(inds, ctx.ns)
+        table = TransposedTable(col0, ctx.ns)
         dx = torch.empty((ctx.ns, c), dtype=torch.float32, device=dy.device)
         dy = dy.contiguous()
-        check(lib.ws_closest_pool_bwd(ptr(dy), nq, h, c, ptr(table.offsets), ptr(table.pairs), ctx.ns, ptr(dx),
+        check(lib.ws_closest_pool_bwd(ptr(dy), nq, 1, c, ptr(table.offsets), ptr(table.pairs), ctx.ns, ptr(dx),
                                       current_stream()))
         return dx, None
 
