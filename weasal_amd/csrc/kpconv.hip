@@ -126,7 +126,15 @@ __device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base,
     return v;
 }
 
-template <int K, int G>
+// K3 forward.  The list phase appends kernel point after kernel point, so the pool is grouped by
+// kernel point; segs[k] marks where k starts.  In the flush phase entry slot s owns the kernel
+// points s, s+S, s+2S, ...: it walks their segments with a float4 register accumulator and stores
+// the finished 16-byte piece of wf[q,k,:] straight to HBM.  No atomics, fixed summation order.
+// (LDS float atomics were measured at ~1 lane/clk on gfx950 -- 3x slower end to end.)
+// The pool holds a full 64-column chunk in the worst case (all K influences non-zero); further
+// column chunks (H > 64) accumulate onto the rows already written.
+constexpr int FPOOL = 64 * 15;
+template <int K, int G, bool DEF>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
@@ -136,64 +144,28 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
 {
     constexpr int CC = 4 * G;      // channels per chunk
     constexpr int S = 64 / G;      // entry slots
-    __shared__ uint2 pool_all[4][POOL];
-    __shared__ __attribute__((aligned(16))) float acc_all[4][K * CC];
+    constexpr int KPS = (K + S - 1) / S;   // kernel points per slot
+    constexpr int KU = 3;          // kernel points per list-phase trip (K % KU == 0)
+    static_assert(K % KU == 0 && K <= 16 && FPOOL >= 64 * K, "pool sizing");
+    __shared__ uint2 pool_all[4][FPOOL];
+    __shared__ int segs_all[4][K + 1];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     uint2* pool = pool_all[wave];
-    float* acc = acc_all[wave];
+    int* segs = segs_all[wave];
     const int j = lane % G;        // 16-byte piece of the row chunk
     const int slot = lane / G;
     const float inv_extent = 1.0f / g.extent;
     const float e2 = g.extent * g.extent;
-    const bool need_pre = g.deformable || g.aggregation == WS_AGGREGATION_CLOSEST;
-
-    for (int i = lane; i < K * CC; i += 64) acc[i] = 0.0f;
-    wave_lds_sync();
-
-    // accumulate pool[0..total) into acc for channel chunk cc0
-    auto flush = [&](int total, int cc0) {
-        wave_lds_sync();
-        const int per = (total + S - 1) / S;
-        const int ch = cc0 + 4 * j;
-        for (int it = 0; it < per; it += 2) {
-            uint2 e[2];
-            float4 v[2];
-            bool ok[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = slot * per + it + u;
-                ok[u] = (it + u) < per && idx < total;
-                e[u] = ok[u] ? pool[idx] : make_uint2(0u, 0u);
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[u]) v[u] = load_row_piece<G>(x, (int64_t)(e[u].x >> 4), ci, ch, vec4);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (ok[u]) {
-                    const float w = __uint_as_float(e[u].y);
-                    float* a = acc + (e[u].x & 15u) * CC + 4 * j;
-                    atomicAdd(a + 0, w * v[u].x);
-                    atomicAdd(a + 1, w * v[u].y);
-                    atomicAdd(a + 2, w * v[u].z);
-                    atomicAdd(a + 3, w * v[u].w);
-                }
-            }
-        }
-        wave_lds_sync();
-    };
+    const bool need_pre = DEF || g.aggregation == WS_AGGREGATION_CLOSEST;
 
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
         const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
-        const float* kp = deformed_kp ? deformed_kp + q * (3 * K) : kernel_points;
-        float mind[K];
-        if (min_d2) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) mind[k] = 3.4e38f;
-        }
+        const float* kp = DEF ? deformed_kp + q * (3 * K) : kernel_points;
         for (int cc0 = 0; cc0 < ci; cc0 += CC) {
-            int total = 0;
+            const int ch = cc0 + 4 * j;
             for (int h0 = 0; h0 < h; h0 += 64) {
+                // ---- list phase: lane = neighbour column
                 const int col = h0 + lane;
                 const bool incol = col < h;
                 const int64_t idx = incol ? inds[q * h + col] : ns;
@@ -205,56 +177,89 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
                 if (need_pre) {
                     float best = 3.4e38f;
                     bool inrange = false;
+#pragma unroll 1
+                    for (int kb = 0; kb < K; kb += KU) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const float d = kp_d2(nx, ny, nz, kp, k);
-                        if (d < best) { best = d; arg = k; }
-                        inrange |= d < e2;
+                        for (int u = 0; u < KU; ++u) {
+                            const float d = kp_d2(nx, ny, nz, kp, kb + u);
+                            if (d < best) { best = d; arg = kb + u; }
+                            inrange |= d < e2;
+                        }
                     }
-                    if (g.deformable) live = live && inrange;
+                    if (DEF) live = live && inrange;
                 }
-                const unsigned tag = (unsigned)(real ? (int)idx : 0) << 4;
+                const unsigned row = (unsigned)(real ? (int)idx : 0);
+                int total = 0;
+#pragma unroll 1
+                for (int kb = 0; kb < K; kb += KU) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float d = kp_d2(nx, ny, nz, kp, k);
-                    if (min_d2 && cc0 == 0 && incol) mind[k] = fminf(mind[k], d);
-                    float w = kp_weight(d, g, inv_extent);
-                    if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
-                    if (!live) w = 0.0f;
-                    const bool nzw = w != 0.0f;
-                    const unsigned long long m = __ballot(nzw);
-                    if (total + 64 > POOL) { flush(total, cc0); total = 0; }
-                    if (nzw) pool[total + lane_rank(m)] = make_uint2(tag | (unsigned)k, __float_as_uint(w));
-                    total += __builtin_popcountll(m);
+                    for (int u = 0; u < KU; ++u) {
+                        const int k = kb + u;
+                        const float d = kp_d2(nx, ny, nz, kp, k);
+                        if (DEF && cc0 == 0) {
+                            float m = incol ? d : 3.4e38f;
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+                            if (lane == 0 && min_d2) min_d2[q * K + k] = h0 == 0 ? m : fminf(min_d2[q * K + k], m);
+                        }
+                        float w = kp_weight(d, g, inv_extent);
+                        if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
+                        if (!live) w = 0.0f;
+                        const bool nzw = w != 0.0f;
+                        const unsigned long long m = __ballot(nzw);
+                        if (lane == 0) segs[k] = total;
+                        if (nzw) pool[total + lane_rank(m)] = make_uint2(row, __float_as_uint(w));
+                        total += __builtin_popcountll(m);
+                    }
                 }
-            }
-            flush(total, cc0);
-            // write wf[q, k, cc0 .. cc0+CC) and clear the accumulator
-            for (int i = lane; i < K * G; i += 64) {
-                const int k = i / G, jj = i - k * G;
-                float4 v = *reinterpret_cast<float4*>(&acc[k * CC + 4 * jj]);
-                *reinterpret_cast<float4*>(&acc[k * CC + 4 * jj]) = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (modulations) { const float md = modulations[q * K + k]; v.x *= md; v.y *= md; v.z *= md; v.w *= md; }
-                const int ch = cc0 + 4 * jj;
-                float* dst = wf + (q * K + k) * ci + ch;
-                if (vec4 && ch + 3 < ci) {
-                    *reinterpret_cast<float4*>(dst) = v;
-                } else {
-                    if (ch + 0 < ci) dst[0] = v.x;
-                    if (ch + 1 < ci) dst[1] = v.y;
-                    if (ch + 2 < ci) dst[2] = v.z;
-                    if (ch + 3 < ci) dst[3] = v.w;
+                if (lane == 0) segs[K] = total;
+                wave_lds_sync();
+                // ---- flush phase: slot owns kernel points slot, slot+S, ...
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk) {
+                    const int k = slot + kk * S;
+                    const bool kok = k < K;
+                    const int beg = kok ? segs[k] : 0;
+                    const int end = kok ? segs[k + 1] : 0;
+                    // wave-uniform trip count = longest segment of this round
+                    int trips = end - beg;
+#pragma unroll
+                    for (int o = 32; o >= G; o >>= 1) trips = max(trips, __shfl_xor(trips, o, 64));
+                    trips = __builtin_amdgcn_readfirstlane(trips);
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int it = 0; it < trips; it += 2) {
+                        uint2 e[2];
+                        float4 v[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const bool ok = beg + it + u < end;
+                            e[u] = ok ? pool[beg + it + u] : make_uint2(0u, 0u);
+                            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (ok) v[u] = load_row_piece<G>(x, (int64_t)e[u].x, ci, ch, vec4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float w = __uint_as_float(e[u].y);
+                            a.x = fmaf(w, v[u].x, a.x); a.y = fmaf(w, v[u].y, a.y);
+                            a.z = fmaf(w, v[u].z, a.z); a.w = fmaf(w, v[u].w, a.w);
+                        }
+                    }
+                    if (kok) {
+                        if (modulations) { const float md = modulations[q * K + k]; a.x *= md; a.y *= md; a.z *= md; a.w *= md; }
+                        float* dst = wf + (q * K + k) * ci + ch;
+                        if (vec4 && ch + 3 < ci) {
+                            float4* d4 = reinterpret_cast<float4*>(dst);
+                            if (h0 > 0) { const float4 o = *d4; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+                            *d4 = a;
+                        } else {
+                            if (ch + 0 < ci) dst[0] = (h0 > 0 ? dst[0] : 0.f) + a.x;
+                            if (ch + 1 < ci) dst[1] = (h0 > 0 ? dst[1] : 0.f) + a.y;
+                            if (ch + 2 < ci) dst[2] = (h0 > 0 ? dst[2] : 0.f) + a.z;
+                            if (ch + 3 < ci) dst[3] = (h0 > 0 ? dst[3] : 0.f) + a.w;
+                        }
+                    }
                 }
-            }
-            wave_lds_sync();
-        }
-        if (min_d2) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float m = mind[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-                if (lane == 0) min_d2[q * K + k] = m;
+                wave_lds_sync();
             }
         }
     }
@@ -273,6 +278,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
 {
     constexpr int CC = 4 * G;
     constexpr int S = 64 / G;
+    constexpr int KU = 3;
+    static_assert(K % KU == 0 && POOL >= 64 * KU + 64, "pool sizing");
     __shared__ uint2 pool_all[4][POOL];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -329,26 +336,33 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
                 if (need_pre) {
                     float best = 3.4e38f;
                     bool inrange = false;
+#pragma unroll 1
+                    for (int kb = 0; kb < K; kb += KU) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const float d = kp_d2(nx, ny, nz, kp, k);
-                        if (d < best) { best = d; arg = k; }
-                        inrange |= d < e2;
+                        for (int u = 0; u < KU; ++u) {
+                            const float d = kp_d2(nx, ny, nz, kp, kb + u);
+                            if (d < best) { best = d; arg = kb + u; }
+                            inrange |= d < e2;
+                        }
                     }
                     if (g.deformable) live = live && inrange;
                 }
+#pragma unroll 1
+                for (int kb = 0; kb < K; kb += KU) {
+                    if (total + 64 * KU > POOL) { flush(total); total = 0; }
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float d = kp_d2(nx, ny, nz, kp, k);
-                    float w = kp_weight(d, g, inv_extent);
-                    if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
-                    if (!live) w = 0.0f;
-                    if (modulations && w != 0.0f) w *= modulations[(int64_t)q * K + k];
-                    const bool nzw = w != 0.0f;
-                    const unsigned long long m = __ballot(nzw);
-                    if (total + 64 > POOL) { flush(total); total = 0; }
-                    if (nzw) pool[total + lane_rank(m)] = make_uint2((unsigned)(q * K + k), __float_as_uint(w));
-                    total += __builtin_popcountll(m);
+                    for (int u = 0; u < KU; ++u) {
+                        const int k = kb + u;
+                        const float d = kp_d2(nx, ny, nz, kp, k);
+                        float w = kp_weight(d, g, inv_extent);
+                        if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
+                        if (!live) w = 0.0f;
+                        if (modulations && w != 0.0f) w *= modulations[(int64_t)q * K + k];
+                        const bool nzw = w != 0.0f;
+                        const unsigned long long m = __ballot(nzw);
+                        if (nzw) pool[total + lane_rank(m)] = make_uint2((unsigned)(q * K + k), __float_as_uint(w));
+                        total += __builtin_popcountll(m);
+                    }
                 }
             }
             flush(total);
@@ -520,9 +534,17 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
     const int grid = ws_grid(nq, 4);
     WS_REQUIRE(ns < (1ll << 27), "ns exceeds the 2^27 rows the entry pool can tag");
     const int vec4 = (ci % 4 == 0) && aligned16(x) && aligned16(wf);
-#define WS_FWD(G)                                                                                              \
-    kpconv_gather_fwd_kernel<15, G><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points, \
-                                                          deformed_kp, modulations, g, wf, min_d2, vec4)
+#define WS_FWD(G)                                                                                                  \
+    do {                                                                                                           \
+        if (deformed_kp)                                                                                           \
+            kpconv_gather_fwd_kernel<15, G, true><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,       \
+                                                                        kernel_points, deformed_kp, modulations, g, \
+                                                                        wf, min_d2, vec4);                         \
+        else                                                                                                       \
+            kpconv_gather_fwd_kernel<15, G, false><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,      \
+                                                                         kernel_points, deformed_kp, modulations, g,\
+                                                                         wf, min_d2, vec4);                        \
+    } while (0)
     if (ci <= 4) WS_FWD(1);
     else if (ci <= 8) WS_FWD(2);
     else if (ci <= 16) WS_FWD(4);
