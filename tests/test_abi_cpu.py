@@ -1,0 +1,121 @@
+"""CPU (no GPU needed): the C-ABI library loads, exports every symbol include/weasal_hip.h
+declares, validates arguments before touching the device, and the numpy facades reject bad
+input with the reference's error type."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "weasal_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ws_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from weasal_amd import _lib
+    names = _declared()
+    assert len(names) >= 20
+    lib = _lib.lib()
+    for n in names:
+        assert hasattr(lib, n), "libweasal_hip.so does not export %s" % n
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in lib.ws_version()
+    assert isinstance(lib.ws_device_count(), int)
+
+
+def test_argument_validation_needs_no_device():
+    from weasal_amd import _lib
+    lib = _lib.lib()
+    null = C.c_void_p(None)
+    one = C.c_void_p(16)     # never dereferenced: validation fails first
+    # K != 15 -> unsupported
+    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 7, null, null, 1.0, 0, 0, one, null, null)
+    assert rc == 2 and b"num_kernel_points" in lib.ws_last_error()
+    # bad extent
+    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 15, null, null, 0.0, 0, 0, one, null, null)
+    assert rc == 1 and b"KP_extent" in lib.ws_last_error()
+    # unknown influence
+    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 15, null, null, 1.0, 9, 0, one, null, null)
+    assert rc == 1
+    # empty query set is a no-op
+    rc = lib.ws_kpconv_gather_fwd(null, 0, one, 4, one, 3, one, 8, one, 15, null, null, 1.0, 0, 0, one, null, null)
+    assert rc == 0
+    assert lib.ws_transpose_scratch_bytes(1000, 10, 500) > 500 * 4
+    with pytest.raises(_lib.WeasalHipError):
+        _lib.check(1)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from weasal_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libweasal_hip.so")
+    with pytest.raises(_lib.WeasalHipError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_operators_refuse_cpu_tensors():
+    import torch
+    from weasal_amd import _lib, ops
+    x = torch.zeros(4, 8)
+    i = torch.zeros(4, 2, dtype=torch.int64)
+    with pytest.raises(_lib.WeasalHipError):
+        ops.max_pool(x, i)
+    with pytest.raises(_lib.WeasalHipError):
+        ops.kpconv_gather(x, torch.zeros(4, 3), torch.zeros(4, 3), i, torch.zeros(15, 3), 1.0)
+    with pytest.raises(_lib.WeasalHipError):
+        ops.radius_neighbors(torch.zeros(4, 3), torch.zeros(4, 3), [4], [4], 1.0)
+
+
+def test_facade_argument_errors():
+    """shape / parsing errors are RuntimeError with the reference's messages (wrapper.cpp:127-171)"""
+    from weasal_amd.cpp_wrappers.cpp_neighbors import radius_neighbors as rn
+    from weasal_amd.cpp_wrappers.cpp_subsampling import grid_subsampling as gs
+    p = np.zeros((5, 3), np.float32)
+    with pytest.raises(RuntimeError, match="query.shape"):
+        rn.batch_query(np.zeros((5, 2)), p, [5], [5], radius=1.0)
+    with pytest.raises(RuntimeError, match="support.shape"):
+        rn.batch_query(p, np.zeros(5), [5], [5], radius=1.0)
+    with pytest.raises(RuntimeError, match="different for queries and supports"):
+        rn.batch_query(p, p, [5], [2, 3], radius=1.0)
+    with pytest.raises(TypeError):
+        rn.batch_query(p, p, [5], [5], 1.0)          # radius is keyword-only ("OOOO|$f")
+    with pytest.raises(RuntimeError, match="points.shape"):
+        gs.subsample_batch(np.zeros((5, 4)), [5], sampleDl=0.1)
+    with pytest.raises(RuntimeError, match="method"):
+        gs.subsample(p, sampleDl=0.1, method="median")
+    with pytest.raises(RuntimeError, match="features.shape"):
+        gs.subsample(p, features=np.zeros((4, 2)), sampleDl=0.1)
+    with pytest.raises(RuntimeError, match="classes.shape"):
+        gs.subsample_batch(p, [5], classes=np.zeros((4,)), sampleDl=0.1)
+
+
+def test_config_derived_fields():
+    from weasal_amd.config import DALESPLConfig, Config
+    c = DALESPLConfig()
+    assert c.num_layers == 5 and c.deform_layers == [False] * 5
+
+    class D(Config):
+        architecture = ['simple', 'resnetb_deformable', 'resnetb_deformable_strided', 'resnetb', 'nearest_upsample', 'unary']
+    d = D()
+    assert d.num_layers == 2 and d.deform_layers == [True, False]
+
+
+def test_kpfcnn_state_dict_keys_match_reference():
+    """the reference checkpoint layout (golden g8 holds the reference's state_dict)"""
+    from conftest import golden
+    from test_oracle_cpu_kpconv import _small_config
+    from weasal_amd.architectures import KPFCNN
+    g8 = golden("g8_kpfcnn.npz")
+    np.random.seed(0)
+    net = KPFCNN(_small_config(), np.arange(9), [])
+    ours = {k for k in net.state_dict() if "num_batches_tracked" not in k}
+    ref = {k[4:] for k in g8.files if k.startswith("sd0/")}
+    assert ours == ref
+    # optimizer split of utils/trainer_PseudoLabel.py:80-81
+    assert not [k for k, _ in net.named_parameters() if 'offset' in k]

@@ -147,3 +147,54 @@ def test_full_size_dales_batch(gpu):
     wp, wl = geom.subsample_batch(p, l, sampleDl=0.8)
     gp, gl = ops.grid_subsample(P, l, 0.8)
     assert np.array_equal(gl, wl) and np.array_equal(gp.cpu().numpy(), wp)
+
+
+def test_numpy_facades_vs_golden(gpu):
+    """the drop-in modules with the reference's call signatures (numpy in / numpy out)"""
+    from weasal_amd.cpp_wrappers.cpp_neighbors import radius_neighbors as cpp_neighbors
+    from weasal_amd.cpp_wrappers.cpp_subsampling import grid_subsampling as cpp_subsampling
+    g = golden("g1_neighbors.npz")
+    got = cpp_neighbors.batch_query(g["points"].astype(np.float64), g["points"], list(g["lens"]), g["lens"], radius=0.6)
+    assert got.dtype == np.int32
+    assert_neighbors_equal(g["points"], g["points"], got, g["self_r0.6"], bool(g["tiefree_self_r0.6"]))
+    with pytest.raises(RuntimeError, match="^Error$"):
+        cpp_neighbors.batch_query(np.array([[9., 9, 9]]), np.zeros((2, 3)), [1], [2], radius=0.1)
+    g3 = golden("g3_subsample_fl.npz")
+    p, l, f, c = cpp_subsampling.subsample_batch(g3["points"], g3["lens"], features=g3["features"],
+                                                 classes=g3["labels"], sampleDl=0.5)
+    assert p.dtype == np.float32 and l.dtype == np.int32 and c.dtype == np.int32 and c.shape == g3["b_labels"].shape
+    assert np.array_equal(p, g3["b_points"]) and np.array_equal(l, g3["b_lens"])
+    assert np.array_equal(f, g3["b_features"]) and np.array_equal(c, g3["b_labels"])
+    p1, f1, c1 = cpp_subsampling.subsample(g3["points"][:420], features=g3["features"][:420],
+                                           classes=g3["labels"][:420], sampleDl=0.5)
+    assert np.array_equal(p1, g3["s_points"]) and np.array_equal(f1, g3["s_features"]) and np.array_equal(c1, g3["s_labels"])
+    pf = cpp_subsampling.subsample(g3["points"][:420], features=g3["features"][:420], sampleDl=0.5)
+    assert isinstance(pf, tuple) and np.array_equal(pf[0], g3["sf_points"]) and np.array_equal(pf[1], g3["sf_features"])
+    only = cpp_subsampling.subsample(g3["points"][:420], sampleDl=0.5)
+    assert isinstance(only, np.ndarray) and np.array_equal(only, g3["s_points"])
+    with pytest.raises(RuntimeError, match="^Error$"):
+        cpp_subsampling.subsample(np.zeros((0, 3), np.float32), sampleDl=0.5)
+
+
+def test_dropin_import_paths(gpu):
+    """with weasal_amd/dropin first on sys.path the reference's import statements resolve here"""
+    import importlib
+    import os
+    import sys
+    from conftest import REPO
+    d = os.path.join(REPO, "weasal_amd", "dropin")
+    sys.path.insert(0, d)
+    try:
+        for name in [m for m in list(sys.modules) if m.split(".")[0] in ("models", "cpp_wrappers", "kernels")]:
+            del sys.modules[name]
+        blocks = importlib.import_module("models.blocks")
+        rn = importlib.import_module("cpp_wrappers.cpp_neighbors.radius_neighbors")
+        gs = importlib.import_module("cpp_wrappers.cpp_subsampling.grid_subsampling")
+        kp = importlib.import_module("kernels.kernel_points")
+        import weasal_amd.blocks
+        assert blocks.KPConv is weasal_amd.blocks.KPConv and callable(rn.batch_query)
+        assert callable(gs.subsample_batch) and callable(kp.load_kernels)
+    finally:
+        sys.path.remove(d)
+        for name in [m for m in list(sys.modules) if m.split(".")[0] in ("models", "cpp_wrappers", "kernels")]:
+            del sys.modules[name]
