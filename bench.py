@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
+    ap.add_argument("--blas", default="", help="torch.backends.cuda.preferred_blas_library (A/B only)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -118,6 +119,8 @@ def main():
     from weasal_amd.architectures import KPFCNN
     from weasal_amd.trainer import make_optimizer, train_step
 
+    if args.blas:
+        torch.backends.cuda.preferred_blas_library(args.blas)
     rank, local_rank, world = dp.init_from_env()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)

@@ -128,6 +128,21 @@ int ws_closest_pool_bwd(const float* dy, int64_t nq, int32_t h, int32_t c,
                         float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Tall-skinny fp32 GEMMs on the f32-input MFMA -- the dense parts of the path:
+ *   the unary 1x1 MLPs  y = x W^T (models/blocks.py:490-501, nn.Linear without bias) and the kernel
+ *   contraction  out = wf[N,15Ci] @ weights[15Ci,Co]  (blocks.py:370-374), plus their autograd.
+ * ws_gemm_xb :  y[m,n] = x[m,k] @ b[k,n]        (b row-major, ld = n; x/y row-major with ldx/ldy)
+ * ws_gemm_xty:  out[k,n] = x[m,k]^T @ y[m,n]    (reduction over the tall dimension m; partial sums per
+ *               row chunk in `scratch` (>= ws_gemm_xty_scratch_bytes), added in a fixed order)
+ * Exact fp32 products and sums (v_mfma_f32_32x32x2_f32), i.e. rocBLAS-equivalent up to summation order.
+ * ------------------------------------------------------------------------------------------ */
+int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+               float* y, int64_t ldy, void* stream);
+int64_t ws_gemm_xty_scratch_bytes(int64_t m, int32_t k, int32_t n);
+int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
+                float* out, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Radius neighbours -- replaces cpp_wrappers/cpp_neighbors (radius_neighbors.batch_query,
  * wrapper.cpp:58-238 -> batch_nanoflann_neighbors, neighbors/neighbors.cpp:211-332).
  * For every query of batch element b: supports j of the same element with

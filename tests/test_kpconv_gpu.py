@@ -147,3 +147,28 @@ def test_large_kpconv_properties(gpu):
     lhs = (dy * b).sum().item()
     rhs = (xg.grad * x2).sum().item()
     assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("m,k,n", [(5000, 64, 32), (70001, 480, 32), (4097, 45, 64), (20000, 384, 128),
+                                   (9000, 128, 9), (12345, 960, 64), (8192, 100, 300)])
+def test_skinny_gemm_vs_float64(gpu, m, k, n):
+    """MFMA f32 GEMMs (forward, dx, dW) against a float64 reference"""
+    from weasal_amd import ops
+    torch.manual_seed(m)
+    x = torch.randn(m, k, device=gpu, requires_grad=True)
+    b = (torch.randn(k, n, device=gpu) / k ** 0.5).requires_grad_(True)
+    dy = torch.randn(m, n, device=gpu)
+    y = ops.matmul(x, b)
+    y.backward(dy)
+    xd, bd, dyd = x.detach().double(), b.detach().double(), dy.double()
+
+    def rel(a, ref):
+        return ((a.double() - ref).abs().max() / ref.abs().max()).item()
+
+    assert rel(y.detach(), xd @ bd) < 2e-6
+    assert rel(x.grad, dyd @ bd.t()) < 2e-6
+    assert rel(b.grad, xd.t() @ dyd) < 2e-5      # m-long fp32 sums
+    # strided x (a column slice) and nn.Linear form
+    w = torch.randn(n, k, device=gpu) / k ** 0.5
+    xs = torch.randn(m, k + 8, device=gpu)[:, 4:4 + k]
+    assert rel(ops.linear(xs, w), xs.double() @ w.double().t()) < 2e-6

@@ -33,6 +33,9 @@ SIGNATURES = {
     "ws_max_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "ws_closest_pool_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
     "ws_closest_pool_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "ws_gemm_xb": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i64, _vp]),
+    "ws_gemm_xty_scratch_bytes": (_i64, [_i64, _i32, _i32]),
+    "ws_gemm_xty": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp]),
     "ws_neighbors_ws_create": (C.c_int, [C.POINTER(_vp)]),
     "ws_neighbors_ws_destroy": (None, [_vp]),
     "ws_radius_neighbors_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32,

@@ -11,7 +11,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .blocks import KPConv, UnaryBlock, block_decider
+from . import ops
+from .blocks import KPConv, NearestUpsampleBlock, UnaryBlock, block_decider, closest_pool
 
 _LAYER_CHANGE = ('pool', 'strided', 'upsample', 'global')
 
@@ -103,6 +104,20 @@ class KPFCNN(nn.Module):
         self.output_loss = 0
         self.reg_loss = 0
         self.l1 = nn.L1Loss()
+        # nearest_upsample -> concat(skip) -> unary is evaluated as
+        #   up(x @ W_x^T) + skip @ W_s^T      (W = [W_x | W_s], the unary's weight)
+        # i.e. the x-part of the 1x1 MLP runs at the coarse resolution and only its (narrower) result
+        # is upsampled; identical in exact arithmetic to architectures.py:339-343 (the gather of a row
+        # commutes with a per-row linear map), ~2.3x fewer decoder FLOPs, no [N_fine, C_up + C_skip] tensor.
+        self.fuse_decoder = True
+
+    def _fused_upsample_unary(self, x, skip, up_block, unary, batch):
+        c_up = x.shape[1]
+        w = unary.mlp.weight
+        y = closest_pool(ops.linear(x, w[:, :c_up]), batch.upsamples[up_block.layer_ind - 1])
+        y = y + ops.linear(skip, w[:, c_up:])
+        y = unary.batch_norm(y)
+        return y if unary.no_relu else unary.leaky_relu(y)
 
     def forward(self, batch, config):
         x = batch.features.clone().detach()
@@ -111,10 +126,20 @@ class KPFCNN(nn.Module):
             if block_i in self.encoder_skips:
                 skips.append(x)
             x = block_op(x, batch)
-        for block_i, block_op in enumerate(self.decoder_blocks):
+        nd = len(self.decoder_blocks)
+        block_i = 0
+        while block_i < nd:
+            block_op = self.decoder_blocks[block_i]
+            nxt = self.decoder_blocks[block_i + 1] if block_i + 1 < nd else None
+            if (self.fuse_decoder and isinstance(block_op, NearestUpsampleBlock) and isinstance(nxt, UnaryBlock)
+                    and (block_i + 1) in self.decoder_concats and block_i not in self.decoder_concats):
+                x = self._fused_upsample_unary(x, skips.pop(), block_op, nxt, batch)
+                block_i += 2
+                continue
             if block_i in self.decoder_concats:
                 x = torch.cat([x, skips.pop()], dim=1)
             x = block_op(x, batch)
+            block_i += 1
         if self.dropout:
             x = self.droplayer(x)
         x = self.head_mlp(x, batch)

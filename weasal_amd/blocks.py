@@ -137,8 +137,8 @@ class KPConv(nn.Module):
         if self.deformable:
             self.min_d2 = min_d2                                                     # blocks.py:304
         # dense contraction over (kernel point, input channel): blocks.py:370-374
-        return torch.matmul(wf.reshape(wf.shape[0], -1),
-                            self.weights.reshape(self.K * self.in_channels, self.out_channels))
+        return ops.matmul(wf.reshape(wf.shape[0], -1),
+                          self.weights.reshape(self.K * self.in_channels, self.out_channels))
 
     def __repr__(self):
         return 'KPConv(radius: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(self.radius, self.in_channels,
@@ -217,7 +217,7 @@ class UnaryBlock(nn.Module):
             self.leaky_relu = nn.LeakyReLU(0.1)
 
     def forward(self, x, batch=None):
-        x = self.batch_norm(self.mlp(x))
+        x = self.batch_norm(ops.linear(x, self.mlp.weight))
         return x if self.no_relu else self.leaky_relu(x)
 
     def __repr__(self):

@@ -10,24 +10,26 @@
 
 namespace {
 
+// pass 1: histogram; the returning atomic also gives every pair its rank inside its list
 __global__ __launch_bounds__(256) void tr_count(const int64_t* __restrict__ inds, int64_t np, int64_t ns,
-                                                 int32_t* __restrict__ counts)
+                                                 int32_t* __restrict__ counts, int32_t* __restrict__ rank)
 {
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < np; p += (int64_t)gridDim.x * 256) {
         const int64_t s = inds[p];
-        if (s < 0 || s >= ns) continue;     // shadow pairs carry no gradient: not tabulated
-        atomicAdd(&counts[s], 1);
+        int r = -1;                               // shadow pairs carry no gradient: not tabulated
+        if (s >= 0 && s < ns) r = atomicAdd(&counts[s], 1);
+        rank[p] = r;
     }
 }
 
-__global__ __launch_bounds__(256) void tr_fill(const int64_t* __restrict__ inds, int64_t np, int64_t ns,
-                                                int32_t* __restrict__ cursor, int32_t* __restrict__ pairs)
+// pass 2 (after the scan): plain scatter, no atomics
+__global__ __launch_bounds__(256) void tr_fill(const int64_t* __restrict__ inds, int64_t np,
+                                                const int32_t* __restrict__ offsets, const int32_t* __restrict__ rank,
+                                                int32_t* __restrict__ pairs)
 {
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < np; p += (int64_t)gridDim.x * 256) {
-        const int64_t s = inds[p];
-        if (s < 0 || s >= ns) continue;
-        const int pos = atomicAdd(&cursor[s], 1);
-        pairs[pos] = (int32_t)p;
+        const int r = rank[p];
+        if (r >= 0) pairs[offsets[inds[p]] + r] = (int32_t)p;
     }
 }
 
@@ -100,9 +102,8 @@ extern "C" {
 
 int64_t ws_transpose_scratch_bytes(int64_t nq, int32_t h, int64_t ns)
 {
-    (void)nq; (void)h;
-    // cursor [ns+2] + scan scratch
-    return (int64_t)sizeof(int32_t) * ((ns + 2) + ws_scan_scratch_items(ns + 1)) + 64;
+        // rank [nq*h] + scan scratch
+    return (int64_t)sizeof(int32_t) * (nq * (int64_t)h + ws_scan_scratch_items(ns + 1)) + 64;
 }
 
 int ws_transpose_build(const int64_t* inds, int64_t nq, int32_t h, int64_t ns, int32_t* t_offsets,
@@ -113,19 +114,18 @@ int ws_transpose_build(const int64_t* inds, int64_t nq, int32_t h, int64_t ns, i
     const int64_t np = nq * (int64_t)h;
     WS_REQUIRE(np < (1ll << 31) && ns < (1ll << 31) - 2, "nq*h or ns exceeds int32");
     hipStream_t st = (hipStream_t)stream;
-    int32_t* cursor = (int32_t*)scratch;
-    int32_t* scan_scratch = cursor + (ns + 2);
+    int32_t* rank = (int32_t*)scratch;
+    int32_t* scan_scratch = rank + np;
     const int64_t nlists = ns + 1;   // list ns = shadow pairs
     WS_HIP(hipMemsetAsync(t_offsets, 0, sizeof(int32_t) * (ns + 2), st));
     if (np > 0) {
-        tr_count<<<ws_grid(np, 256), 256, 0, st>>>(inds, np, ns, t_offsets);
+        tr_count<<<ws_grid(np, 256), 256, 0, st>>>(inds, np, ns, t_offsets, rank);
         WS_LAUNCH_CHECK();
     }
     int rc = ws_exclusive_scan_i32(t_offsets, t_offsets, nlists, scan_scratch, st);
     if (rc) return rc;
     if (np > 0) {
-        WS_HIP(hipMemcpyAsync(cursor, t_offsets, sizeof(int32_t) * (ns + 2), hipMemcpyDeviceToDevice, st));
-        tr_fill<<<ws_grid(np, 256), 256, 0, st>>>(inds, np, ns, cursor, t_pairs);
+        tr_fill<<<ws_grid(np, 256), 256, 0, st>>>(inds, np, t_offsets, rank, t_pairs);
         WS_LAUNCH_CHECK();
         // the shadow list (slot ns) is never read by a backward kernel: not sorted
         tr_sort_lists<<<ws_grid(ns, 4), 256, 0, st>>>(t_offsets, ns, t_pairs);

@@ -162,6 +162,61 @@ def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linea
 
 
 # ------------------------------------------------------------------------------------------------
+# tall-skinny GEMMs (unary MLPs and the kernel contraction) on the f32 MFMA
+# ------------------------------------------------------------------------------------------------
+GEMM_MIN_ROWS = 4096     # below this the operand is no longer "tall": plain torch.matmul (rocBLAS)
+
+
+def _gemm_xb(x, b):
+    lib = _lib.lib()
+    m, k = x.shape
+    n = b.shape[1]
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(lib.ws_gemm_xb(ptr(x), m, k, x.stride(0), ptr(b), n, ptr(y), n, current_stream()))
+    return y
+
+
+class _MatmulXB(torch.autograd.Function):
+    """y = x @ b with x [M,K] tall and b [K,N] small; dx = dy @ b^T, db = x^T @ dy"""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        xc = x if (x.stride(1) == 1 and x.stride(0) >= x.shape[1]) else x.contiguous()
+        bc = b.contiguous()
+        ctx.save_for_backward(xc, bc)
+        return _gemm_xb(xc, bc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.lib()
+        x, b = ctx.saved_tensors
+        dy = dy if (dy.stride(1) == 1 and dy.stride(0) >= dy.shape[1]) else dy.contiguous()
+        dx = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm_xb(dy, b.t().contiguous())
+        if ctx.needs_input_grad[1]:
+            m, k = x.shape
+            n = dy.shape[1]
+            db = torch.empty((k, n), dtype=torch.float32, device=x.device)
+            scratch = torch.empty(max(lib.ws_gemm_xty_scratch_bytes(m, k, n), 16), dtype=torch.uint8, device=x.device)
+            check(lib.ws_gemm_xty(ptr(x), m, k, x.stride(0), ptr(dy), n, dy.stride(0), ptr(db), ptr(scratch),
+                                  current_stream()))
+        return dx, db
+
+
+def matmul(x, b):
+    """x [M,K] @ b [K,N]: the MFMA kernels for tall device operands, torch.matmul otherwise"""
+    if x.is_cuda and x.dim() == 2 and b.dim() == 2 and x.shape[0] >= GEMM_MIN_ROWS and x.dtype == torch.float32:
+        return _MatmulXB.apply(x, b)
+    return torch.matmul(x, b)
+
+
+def linear(x, weight):
+    """x @ weight^T (nn.Linear without bias; weight is [out, in])"""
+    return matmul(x, weight.t())
+
+
+# ------------------------------------------------------------------------------------------------
 # pooling helpers (K7)
 # ------------------------------------------------------------------------------------------------
 class _MaxPool(torch.autograd.Function):
