@@ -69,6 +69,9 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
                          const float* deformed_kp,    /* NULL = rigid */
                          const float* modulations,    /* NULL = none  */
                          float extent, int32_t influence, int32_t aggregation,
+                         const int32_t* order,        /* NULL or a permutation of [0,nq): the order in which
+                                                         queries are scheduled (results do not depend on it;
+                                                         a spatial order keeps gathered rows in L2) */
                          float* wf,                   /* out [nq,k,ci] */
                          float* min_d2,               /* out [nq,k] or NULL */
                          void* stream);
@@ -81,6 +84,7 @@ int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, i
                            const float* kernel_points, int32_t k,
                            const float* deformed_kp, const float* modulations,
                            float extent, int32_t influence, int32_t aggregation,
+                           const int32_t* order,      /* NULL or a permutation of [0,ns): scheduling order */
                            float* dx,                 /* out [ns,ci] (fully overwritten) */
                            void* stream);
 
@@ -168,6 +172,18 @@ int ws_radius_neighbors_plan(ws_neighbors_ws* ws,
                              float radius, int32_t* h_max_count, void* stream);
 int ws_radius_neighbors_fill(ws_neighbors_ws* ws, int32_t width,
                              int32_t* out_i32, int64_t* out_i64, void* stream);
+/* One-call form for callers that crop anyway (datasets/common.py:336-346): builds the grid and makes
+ * ONE query pass that writes out[nq,width] (rows padded with ns) and counts at the same time;
+ * synchronises and returns the true *h_max_count -- if it is smaller than `width` the caller keeps the
+ * first max_count columns (the rest is padding).  WS_ERR_EMPTY as above. */
+int ws_radius_neighbors_search(ws_neighbors_ws* ws,
+                               const float* queries, int64_t nq, const float* supports, int64_t ns,
+                               const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                               float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
+                               int32_t* h_max_count, void* stream);
+/* supports of the last plan/search in cell order (device int32 [ns], a permutation): a spatially
+ * coherent scheduling order for the kernels that take `order`. */
+int ws_radius_neighbors_order(const ws_neighbors_ws* ws, int32_t* out_order, void* stream);
 /* per-query neighbour counts of the last plan (device int32 [nq]); valid until the next plan.
  * Feeds the neighbourhood-limit calibration (datasets/DALES_PseudoLabel.py:1238-1240). */
 const int32_t* ws_radius_neighbors_counts(const ws_neighbors_ws* ws);

@@ -35,16 +35,16 @@ def test_argument_validation_needs_no_device():
     null = C.c_void_p(None)
     one = C.c_void_p(16)     # never dereferenced: validation fails first
     # K != 15 -> unsupported
-    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 7, null, null, 1.0, 0, 0, one, null, null)
+    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 7, null, null, 1.0, 0, 0, null, one, null, null)
     assert rc == 2 and b"num_kernel_points" in lib.ws_last_error()
     # bad extent
-    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 15, null, null, 0.0, 0, 0, one, null, null)
+    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 15, null, null, 0.0, 0, 0, null, one, null, null)
     assert rc == 1 and b"KP_extent" in lib.ws_last_error()
     # unknown influence
-    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 15, null, null, 1.0, 9, 0, one, null, null)
+    rc = lib.ws_kpconv_gather_fwd(one, 4, one, 4, one, 3, one, 8, one, 15, null, null, 1.0, 9, 0, null, one, null, null)
     assert rc == 1
     # empty query set is a no-op
-    rc = lib.ws_kpconv_gather_fwd(null, 0, one, 4, one, 3, one, 8, one, 15, null, null, 1.0, 0, 0, one, null, null)
+    rc = lib.ws_kpconv_gather_fwd(null, 0, one, 4, one, 3, one, 8, one, 15, null, null, 1.0, 0, 0, null, one, null, null)
     assert rc == 0
     assert lib.ws_transpose_scratch_bytes(1000, 10, 500) > 500 * 4
     with pytest.raises(_lib.WeasalHipError):

@@ -22,9 +22,9 @@ SIGNATURES = {
     "ws_version": (C.c_char_p, []),
     "ws_device_count": (C.c_int, []),
     "ws_kpconv_gather_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp,
-                                      _f32, _i32, _i32, _vp, _vp, _vp]),
+                                      _f32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ws_kpconv_gather_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32,
-                                        _vp, _vp, _f32, _i32, _i32, _vp, _vp]),
+                                        _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp]),
     "ws_kpconv_gather_bwd_geom": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _i32,
                                            _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp]),
     "ws_transpose_scratch_bytes": (_i64, [_i64, _i32, _i64]),
@@ -41,6 +41,9 @@ SIGNATURES = {
     "ws_radius_neighbors_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32,
                                           C.POINTER(_i32), _vp]),
     "ws_radius_neighbors_fill": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
+    "ws_radius_neighbors_search": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp,
+                                            C.POINTER(_i32), _vp]),
+    "ws_radius_neighbors_order": (C.c_int, [_vp, _vp, _vp]),
     "ws_radius_neighbors_counts": (_vp, [_vp]),
     "ws_subsample_ws_create": (C.c_int, [C.POINTER(_vp)]),
     "ws_subsample_ws_destroy": (None, [_vp]),

@@ -110,19 +110,21 @@ __device__ __forceinline__ float kp_d2(float nx, float ny, float nz, const float
     return (dx * dx + dy * dy) + dz * dz;
 }
 
-template <int G>
-__device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base, int64_t row, int ci, int ch, int vec4)
+// 16-byte piece of a feature row, branch free.  VEC: the caller guarantees ch+3 < ci (or passes
+// ch = 0 together with a zero weight).  !VEC: element-wise with clamped columns; columns >= ci
+// are zeroed.
+template <bool VEC>
+__device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base, int64_t row, int ci, int ch)
 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* src = base + row * ci + ch;
-    if (vec4 && ch + 3 < ci) {
-        v = *reinterpret_cast<const float4*>(src);
-    } else {
-        if (ch + 0 < ci) v.x = src[0];
-        if (ch + 1 < ci) v.y = src[1];
-        if (ch + 2 < ci) v.z = src[2];
-        if (ch + 3 < ci) v.w = src[3];
-    }
+    const float* src = base + row * ci;
+    if (VEC) return *reinterpret_cast<const float4*>(src + ch);
+    float4 v;
+    const int last = ci - 1;
+    v.x = src[min(ch + 0, last)]; v.y = src[min(ch + 1, last)]; v.z = src[min(ch + 2, last)]; v.w = src[min(ch + 3, last)];
+    if (ch + 0 >= ci) v.x = 0.f;
+    if (ch + 1 >= ci) v.y = 0.f;
+    if (ch + 2 >= ci) v.z = 0.f;
+    if (ch + 3 >= ci) v.w = 0.f;
     return v;
 }
 
@@ -131,23 +133,27 @@ __device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base,
 // points s, s+S, s+2S, ...: it walks their segments with a float4 register accumulator and stores
 // the finished 16-byte piece of wf[q,k,:] straight to HBM.  No atomics, fixed summation order.
 // (LDS float atomics were measured at ~1 lane/clk on gfx950 -- 3x slower end to end.)
-// The pool holds a full 64-column chunk in the worst case (all K influences non-zero); further
-// column chunks (H > 64) accumulate onto the rows already written.
-constexpr int FPOOL = 64 * 15;
-template <int K, int G, bool DEF>
+// The pool (256 entries, ~4x the typical load of a 64-column chunk) is built once per column chunk
+// and flushed for every 4*G-channel chunk; if it would overflow (dense influence modes, collapsed
+// deformed kernels) the finished segments are flushed early and later flushes accumulate onto the
+// rows already written, as do further column chunks (H > 64).
+// The kernel is latency bound (index -> neighbour xyz -> feature rows are dependent gathers), so
+// the index and xyz loads of the next two items are software-prefetched under the current item.
+constexpr int FPOOL = 256;
+template <int K, int G, bool DEF, bool VEC>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
     const float* __restrict__ kernel_points, const float* __restrict__ deformed_kp,
     const float* __restrict__ modulations, GeomParams g, float* __restrict__ wf,
-    float* __restrict__ min_d2, int vec4)
+    float* __restrict__ min_d2, const int32_t* __restrict__ order)
 {
     constexpr int CC = 4 * G;      // channels per chunk
     constexpr int S = 64 / G;      // entry slots
     constexpr int KPS = (K + S - 1) / S;   // kernel points per slot
     constexpr int KU = 3;          // kernel points per list-phase trip (K % KU == 0)
-    static_assert(K % KU == 0 && K <= 16 && FPOOL >= 64 * K, "pool sizing");
-    __shared__ uint2 pool_all[4][FPOOL];
+    static_assert(K % KU == 0 && K <= 16 && FPOOL >= 64 * KU + 64, "pool sizing");
+    __shared__ uint2 pool_all[4][FPOOL + 8];   // +8: the branch-free flush may read (and ignore) past the end
     __shared__ int segs_all[4][K + 1];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -159,128 +165,179 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float e2 = g.extent * g.extent;
     const bool need_pre = DEF || g.aggregation == WS_AGGREGATION_CLOSEST;
 
-    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
-        const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
-        const float* kp = DEF ? deformed_kp + q * (3 * K) : kernel_points;
+    int64_t ibeg, iend;
+    ws_block_range(nq, ibeg, iend);
+
+    // flush the pool: every slot walks the segments of its kernel points for all channel chunks.
+    // maxlen = longest segment (wave-uniform): every round runs that many steps, lanes past the end
+    // of their own segment carry weight 0 and read row 0 -- no divergent branches in the loop.
+    auto flush = [&](int64_t q, bool accumulate, int maxlen) {
+        wave_lds_sync();
         for (int cc0 = 0; cc0 < ci; cc0 += CC) {
             const int ch = cc0 + 4 * j;
-            for (int h0 = 0; h0 < h; h0 += 64) {
-                // ---- list phase: lane = neighbour column
-                const int col = h0 + lane;
-                const bool incol = col < h;
-                const int64_t idx = incol ? inds[q * h + col] : ns;
-                const bool real = incol && idx < ns && idx >= 0;
-                float nx = WS_SHADOW - qx, ny = WS_SHADOW - qy, nz = WS_SHADOW - qz;
-                if (real) { nx = s_pts[3 * idx] - qx; ny = s_pts[3 * idx + 1] - qy; nz = s_pts[3 * idx + 2] - qz; }
-                bool live = real;
-                int arg = 0;
-                if (need_pre) {
-                    float best = 3.4e38f;
-                    bool inrange = false;
-#pragma unroll 1
-                    for (int kb = 0; kb < K; kb += KU) {
+            const bool chok = VEC ? (ch + 3 < ci) : (ch < ci);
+            const int chl = chok ? ch : 0;
 #pragma unroll
-                        for (int u = 0; u < KU; ++u) {
-                            const float d = kp_d2(nx, ny, nz, kp, kb + u);
-                            if (d < best) { best = d; arg = kb + u; }
-                            inrange |= d < e2;
-                        }
+            for (int kk = 0; kk < KPS; ++kk) {
+                const int k = slot + kk * S;
+                const bool kok = k < K && chok;
+                const int beg = kok ? segs[k] : 0;
+                const int end = kok ? segs[k + 1] : 0;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int it = 0; it < maxlen; it += 4) {
+                    uint2 e[4];
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        e[u] = pool[beg + it + u];
+                        const bool ok = beg + it + u < end;
+                        e[u].x = ok ? e[u].x : 0u;
+                        e[u].y = ok ? e[u].y : 0u;                    // weight 0.0f
+                        v[u] = load_row_piece<VEC>(x, (int64_t)e[u].x, ci, chl);
                     }
-                    if (DEF) live = live && inrange;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float w = __uint_as_float(e[u].y);
+                        a.x = fmaf(w, v[u].x, a.x); a.y = fmaf(w, v[u].y, a.y);
+                        a.z = fmaf(w, v[u].z, a.z); a.w = fmaf(w, v[u].w, a.w);
+                    }
                 }
-                const unsigned row = (unsigned)(real ? (int)idx : 0);
-                int total = 0;
+                if (kok) {
+                    if (modulations) { const float md = modulations[q * K + k]; a.x *= md; a.y *= md; a.z *= md; a.w *= md; }
+                    float* dst = wf + (q * K + k) * ci + ch;
+                    if (VEC) {
+                        float4* d4 = reinterpret_cast<float4*>(dst);
+                        if (accumulate) { const float4 o = *d4; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+                        *d4 = a;
+                    } else {
+                        if (ch + 0 < ci) dst[0] = (accumulate ? dst[0] : 0.f) + a.x;
+                        if (ch + 1 < ci) dst[1] = (accumulate ? dst[1] : 0.f) + a.y;
+                        if (ch + 2 < ci) dst[2] = (accumulate ? dst[2] : 0.f) + a.z;
+                        if (ch + 3 < ci) dst[3] = (accumulate ? dst[3] : 0.f) + a.w;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+    };
+
+    // ---- software pipeline over the items of this wave: idx two items ahead, xyz one item ahead
+    auto item_q = [&](int64_t it) -> int64_t { return it < iend ? (order ? (int64_t)order[it] : it) : -1; };
+    auto load_idx = [&](int64_t q) -> int {
+        if (q < 0 || lane >= h) return -1;
+        const int64_t v = inds[q * h + lane];
+        return (v >= 0 && v < ns) ? (int)v : -1;
+    };
+    auto load_pt = [&](int idx, float& px, float& py, float& pz) {
+        px = py = pz = WS_SHADOW;
+        if (idx >= 0) { px = s_pts[3 * (int64_t)idx]; py = s_pts[3 * (int64_t)idx + 1]; pz = s_pts[3 * (int64_t)idx + 2]; }
+    };
+    int64_t q0 = item_q(ibeg + wave), q1 = item_q(ibeg + wave + 4);
+    int idx0 = load_idx(q0), idx1 = load_idx(q1);
+    float p0x, p0y, p0z;
+    load_pt(idx0, p0x, p0y, p0z);
+
+    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+        const int64_t q = q0;
+        // prefetch: idx of item+8, xyz of item+4
+        const int64_t q2 = item_q(item + 8);
+        const int idx2 = load_idx(q2);
+        float p1x, p1y, p1z;
+        load_pt(idx1, p1x, p1y, p1z);
+
+        const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
+        const float* kp = DEF ? deformed_kp + q * (3 * K) : kernel_points;
+        bool accumulate = false;
+        for (int h0 = 0; h0 < h; h0 += 64) {
+            // ---- list phase: lane = neighbour column
+            const int col = h0 + lane;
+            const bool incol = col < h;
+            int idx = idx0;
+            float px = p0x, py = p0y, pz = p0z;
+            if (h0 > 0) {      // further column chunks are loaded on demand
+                idx = -1;
+                if (incol) { const int64_t v = inds[q * h + col]; idx = (v >= 0 && v < ns) ? (int)v : -1; }
+                load_pt(idx, px, py, pz);
+            }
+            const bool real = incol && idx >= 0;
+            const float nx = px - qx, ny = py - qy, nz = pz - qz;
+            bool live = real;
+            int arg = 0;
+            if (need_pre) {
+                float best = 3.4e38f;
+                bool inrange = false;
 #pragma unroll 1
                 for (int kb = 0; kb < K; kb += KU) {
 #pragma unroll
                     for (int u = 0; u < KU; ++u) {
-                        const int k = kb + u;
-                        const float d = kp_d2(nx, ny, nz, kp, k);
-                        if (DEF && cc0 == 0) {
-                            float m = incol ? d : 3.4e38f;
-#pragma unroll
-                            for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-                            if (lane == 0 && min_d2) min_d2[q * K + k] = h0 == 0 ? m : fminf(min_d2[q * K + k], m);
-                        }
-                        float w = kp_weight(d, g, inv_extent);
-                        if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
-                        if (!live) w = 0.0f;
-                        const bool nzw = w != 0.0f;
-                        const unsigned long long m = __ballot(nzw);
-                        if (lane == 0) segs[k] = total;
-                        if (nzw) pool[total + lane_rank(m)] = make_uint2(row, __float_as_uint(w));
-                        total += __builtin_popcountll(m);
+                        const float d = kp_d2(nx, ny, nz, kp, kb + u);
+                        if (d < best) { best = d; arg = kb + u; }
+                        inrange |= d < e2;
                     }
                 }
-                if (lane == 0) segs[K] = total;
-                wave_lds_sync();
-                // ---- flush phase: slot owns kernel points slot, slot+S, ...
-#pragma unroll
-                for (int kk = 0; kk < KPS; ++kk) {
-                    const int k = slot + kk * S;
-                    const bool kok = k < K;
-                    const int beg = kok ? segs[k] : 0;
-                    const int end = kok ? segs[k + 1] : 0;
-                    // wave-uniform trip count = longest segment of this round
-                    int trips = end - beg;
-#pragma unroll
-                    for (int o = 32; o >= G; o >>= 1) trips = max(trips, __shfl_xor(trips, o, 64));
-                    trips = __builtin_amdgcn_readfirstlane(trips);
-                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int it = 0; it < trips; it += 2) {
-                        uint2 e[2];
-                        float4 v[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const bool ok = beg + it + u < end;
-                            e[u] = ok ? pool[beg + it + u] : make_uint2(0u, 0u);
-                            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (ok) v[u] = load_row_piece<G>(x, (int64_t)e[u].x, ci, ch, vec4);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const float w = __uint_as_float(e[u].y);
-                            a.x = fmaf(w, v[u].x, a.x); a.y = fmaf(w, v[u].y, a.y);
-                            a.z = fmaf(w, v[u].z, a.z); a.w = fmaf(w, v[u].w, a.w);
-                        }
-                    }
-                    if (kok) {
-                        if (modulations) { const float md = modulations[q * K + k]; a.x *= md; a.y *= md; a.z *= md; a.w *= md; }
-                        float* dst = wf + (q * K + k) * ci + ch;
-                        if (vec4 && ch + 3 < ci) {
-                            float4* d4 = reinterpret_cast<float4*>(dst);
-                            if (h0 > 0) { const float4 o = *d4; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
-                            *d4 = a;
-                        } else {
-                            if (ch + 0 < ci) dst[0] = (h0 > 0 ? dst[0] : 0.f) + a.x;
-                            if (ch + 1 < ci) dst[1] = (h0 > 0 ? dst[1] : 0.f) + a.y;
-                            if (ch + 2 < ci) dst[2] = (h0 > 0 ? dst[2] : 0.f) + a.z;
-                            if (ch + 3 < ci) dst[3] = (h0 > 0 ? dst[3] : 0.f) + a.w;
-                        }
-                    }
-                }
-                wave_lds_sync();
+                if (DEF) live = live && inrange;
             }
+            const unsigned row = (unsigned)(real ? idx : 0);
+            int total = 0, maxlen = 0;
+#pragma unroll 1
+            for (int kb = 0; kb < K; kb += KU) {
+                if (total + 64 * KU > FPOOL) {
+                    // early flush of the finished segments; the rest of this chunk accumulates
+                    for (int k2 = kb; k2 <= K; ++k2) segs[k2] = total;
+                    flush(q, accumulate, maxlen);
+                    accumulate = true;
+                    for (int k2 = 0; k2 < kb; ++k2) segs[k2] = 0;
+                    total = 0; maxlen = 0;
+                }
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    const int k = kb + u;
+                    const float d = kp_d2(nx, ny, nz, kp, k);
+                    if (DEF) {
+                        float m = incol ? d : 3.4e38f;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+                        if (lane == 0 && min_d2) min_d2[q * K + k] = h0 == 0 ? m : fminf(min_d2[q * K + k], m);
+                    }
+                    float w = kp_weight(d, g, inv_extent);
+                    if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
+                    if (!live) w = 0.0f;
+                    const bool nzw = w != 0.0f;
+                    const unsigned long long m = __ballot(nzw);
+                    segs[k] = total;                                   // every lane, same value
+                    if (nzw) pool[total + lane_rank(m)] = make_uint2(row, __float_as_uint(w));
+                    const int c = __builtin_popcountll(m);
+                    total += c;
+                    maxlen = max(maxlen, c);
+                }
+            }
+            segs[K] = total;
+            flush(q, accumulate, maxlen);
+            accumulate = true;
         }
+        // rotate the pipeline
+        q0 = q1; q1 = q2;
+        idx0 = idx1; idx1 = idx2;
+        p0x = p1x; p0y = p1y; p0z = p1z;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // K4 backward w.r.t. x through the transposed table: dx[s, :] = sum_e weight_e * dwf[row_e, :]
 // ---------------------------------------------------------------------------------------------
-template <int K, int G>
+template <int K, int G, bool VEC>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     int h, const int32_t* __restrict__ t_offsets, const int32_t* __restrict__ t_pairs,
     const float* __restrict__ dwf, int ci, const float* __restrict__ kernel_points,
     const float* __restrict__ deformed_kp, const float* __restrict__ modulations, GeomParams g,
-    float* __restrict__ dx, int vec4)
+    float* __restrict__ dx, const int32_t* __restrict__ order)
 {
     constexpr int CC = 4 * G;
     constexpr int S = 64 / G;
     constexpr int KU = 3;
     static_assert(K % KU == 0 && POOL >= 64 * KU + 64, "pool sizing");
-    __shared__ uint2 pool_all[4][POOL];
+    __shared__ uint2 pool_all[4][POOL + 8];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     uint2* pool = pool_all[wave];
@@ -290,26 +347,35 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
     const float e2 = g.extent * g.extent;
     const bool need_pre = g.deformable || g.aggregation == WS_AGGREGATION_CLOSEST;
 
-    for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < ns; s += (int64_t)gridDim.x * 4) {
+    int64_t ibeg, iend;
+    ws_block_range(ns, ibeg, iend);
+    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+        const int64_t s = order ? (int64_t)order[item] : item;
         const float sx = s_pts[3 * s + 0], sy = s_pts[3 * s + 1], sz = s_pts[3 * s + 2];
         const int beg = t_offsets[s], end = t_offsets[s + 1];
         for (int cc0 = 0; cc0 < ci; cc0 += CC) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             const int ch = cc0 + 4 * j;
+            const bool chok = VEC ? (ch + 3 < ci) : (ch < ci);
+            const int chl = chok ? ch : 0;
+            // balanced, branch-free flush: slot s takes entries [s*per, (s+1)*per); entries past the
+            // end carry weight 0 and read row 0
             auto flush = [&](int total) {
                 wave_lds_sync();
                 const int per = (total + S - 1) / S;
+                const int lo = slot * per;
+                const int hi = chok ? min(lo + per, total) : lo;
                 for (int it = 0; it < per; it += 4) {
                     float4 v[4];
                     float w[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int idx = slot * per + it + u;
-                        const bool ok = (it + u) < per && idx < total;
-                        const uint2 e = ok ? pool[idx] : make_uint2(0u, 0u);
+                        const int idx = min(lo + it + u, POOL + 7);
+                        uint2 e = pool[idx];
+                        const bool ok = lo + it + u < hi;
+                        e.x = ok ? e.x : 0u;
                         w[u] = ok ? __uint_as_float(e.y) : 0.0f;
-                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (ok) v[u] = load_row_piece<G>(dwf, (int64_t)e.x, ci, ch, vec4);
+                        v[u] = load_row_piece<VEC>(dwf, (int64_t)e.x, ci, chl);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -376,8 +442,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
             }
             if (slot == 0) {
                 float* dst = dx + s * ci + ch;
-                if (vec4 && ch + 3 < ci) {
-                    *reinterpret_cast<float4*>(dst) = acc;
+                if (VEC) {
+                    if (chok) *reinterpret_cast<float4*>(dst) = acc;
                 } else {
                     if (ch + 0 < ci) dst[0] = acc.x;
                     if (ch + 1 < ci) dst[1] = acc.y;
@@ -523,7 +589,7 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
                          const int64_t* inds, int32_t h, const float* x, int32_t ci,
                          const float* kernel_points, int32_t k, const float* deformed_kp,
                          const float* modulations, float extent, int32_t influence, int32_t aggregation,
-                         float* wf, float* min_d2, void* stream)
+                         const int32_t* order, float* wf, float* min_d2, void* stream)
 {
     int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, influence, aggregation);
     if (rc) return rc;
@@ -534,22 +600,21 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
     const int grid = ws_grid(nq, 4);
     WS_REQUIRE(ns < (1ll << 27), "ns exceeds the 2^27 rows the entry pool can tag");
     const int vec4 = (ci % 4 == 0) && aligned16(x) && aligned16(wf);
-#define WS_FWD(G)                                                                                                  \
-    do {                                                                                                           \
-        if (deformed_kp)                                                                                           \
-            kpconv_gather_fwd_kernel<15, G, true><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,       \
-                                                                        kernel_points, deformed_kp, modulations, g, \
-                                                                        wf, min_d2, vec4);                         \
-        else                                                                                                       \
-            kpconv_gather_fwd_kernel<15, G, false><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,      \
-                                                                         kernel_points, deformed_kp, modulations, g,\
-                                                                         wf, min_d2, vec4);                        \
+#define WS_FWD2(G, DEFV, VECV)                                                                                     \
+    kpconv_gather_fwd_kernel<15, G, DEFV, VECV><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,           \
+                                                                      kernel_points, deformed_kp, modulations, g, wf, \
+                                                                      min_d2, order)
+#define WS_FWD(G)                                                         \
+    do {                                                                  \
+        if (deformed_kp) { if (vec4) WS_FWD2(G, true, true); else WS_FWD2(G, true, false); }    \
+        else { if (vec4) WS_FWD2(G, false, true); else WS_FWD2(G, false, false); }              \
     } while (0)
     if (ci <= 4) WS_FWD(1);
     else if (ci <= 8) WS_FWD(2);
     else if (ci <= 16) WS_FWD(4);
     else if (ci <= 32) WS_FWD(8);
     else WS_FWD(16);
+#undef WS_FWD2
 #undef WS_FWD
     WS_LAUNCH_CHECK();
     return WS_OK;
@@ -559,7 +624,7 @@ int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, i
                            const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
                            const float* dwf, int32_t ci, const float* kernel_points, int32_t k,
                            const float* deformed_kp, const float* modulations, float extent,
-                           int32_t influence, int32_t aggregation, float* dx, void* stream)
+                           int32_t influence, int32_t aggregation, const int32_t* order, float* dx, void* stream)
 {
     (void)inds;
     int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, influence, aggregation);
@@ -571,14 +636,19 @@ int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, i
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && aligned16(dwf) && aligned16(dx);
-#define WS_BWD(G)                                                                                               \
-    kpconv_gather_bwd_x_kernel<15, G><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, dwf, ci, \
-                                                            kernel_points, deformed_kp, modulations, g, dx, vec4)
+#define WS_BWD2(G, VECV)                                                                                              \
+    kpconv_gather_bwd_x_kernel<15, G, VECV><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, dwf, ci, \
+                                                                  kernel_points, deformed_kp, modulations, g, dx, order)
+#define WS_BWD(G)                                        \
+    do {                                                 \
+        if (vec4) WS_BWD2(G, true); else WS_BWD2(G, false); \
+    } while (0)
     if (ci <= 4) WS_BWD(1);
     else if (ci <= 8) WS_BWD(2);
     else if (ci <= 16) WS_BWD(4);
     else if (ci <= 32) WS_BWD(8);
     else WS_BWD(16);
+#undef WS_BWD2
 #undef WS_BWD
     WS_LAUNCH_CHECK();
     return WS_OK;

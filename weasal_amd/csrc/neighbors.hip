@@ -171,11 +171,15 @@ __global__ __launch_bounds__(256) void nb_count_kernel(const float* __restrict__
                                                         const CloudGrid* __restrict__ grids, int nb,
                                                         const int32_t* __restrict__ cell_start,
                                                         const float4* __restrict__ sorted, float r2,
+                                                        const int32_t* __restrict__ qorder,
                                                         int32_t* __restrict__ counts, int32_t* __restrict__ max_count)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int local_max = 0;
-    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
+    int64_t ibeg, iend;
+    ws_block_range(nq, ibeg, iend);
+    for (int64_t it = ibeg + wave; it < iend; it += 4) {
+        const int64_t q = qorder ? (int64_t)qorder[it] : it;
         const int b = find_cloud_q(grids, nb, q);
         const CloudGrid g = grids[b];
         const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
@@ -197,12 +201,17 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
                                                        const CloudGrid* __restrict__ grids, int nb,
                                                        const int32_t* __restrict__ cell_start,
                                                        const float4* __restrict__ sorted, float r2, int64_t ns,
-                                                       int width, OutT* __restrict__ out)
+                                                       int width, const int32_t* __restrict__ qorder, OutT* __restrict__ out,
+                                                       int32_t* __restrict__ counts, int32_t* __restrict__ max_count)
 {
     __shared__ unsigned long long slab_all[4][CAP];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned long long* slab = slab_all[wave];
-    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
+    int local_max = 0;
+    int64_t ibeg, iend;
+    ws_block_range(nq, ibeg, iend);
+    for (int64_t it = ibeg + wave; it < iend; it += 4) {
+        const int64_t q = qorder ? (int64_t)qorder[it] : it;
         const int b = find_cloud_q(grids, nb, q);
         const CloudGrid g = grids[b];
         const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
@@ -219,6 +228,10 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
                 }
                 cnt += __builtin_popcountll(m);
             });
+        }
+        if (counts) {      // fused search: the true count (may exceed CAP -> the host reruns wider)
+            if (lane == 0) counts[q] = cnt;
+            local_max = max(local_max, cnt);
         }
         cnt = min(cnt, CAP);
         int m = 64;
@@ -247,6 +260,13 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if (max_count && lane == 0 && local_max > 0) atomicMax(max_count, local_max);
+}
+
+__global__ __launch_bounds__(256) void nb_order_kernel(const float4* __restrict__ sorted, int64_t ns, int32_t* __restrict__ order)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ns; i += (int64_t)gridDim.x * 256)
+        order[i] = __float_as_int(sorted[i].w);
 }
 
 template <typename T>
@@ -273,6 +293,8 @@ struct ws_neighbors_ws {
     DevBuf<float> bbox;
     DevBuf<int32_t> cell_of, cell_start, cursor, counts, scan_scratch, max_count;
     DevBuf<float4> sorted;
+    DevBuf<int32_t> order;        // supports in cell order (work order of self-queries)
+    bool self_query = false;      // queries == supports: walk the queries in cell order
     // state of the last plan
     const float* queries = nullptr;
     int64_t nq = 0, ns = 0;
@@ -295,21 +317,20 @@ void ws_neighbors_ws_destroy(ws_neighbors_ws* ws)
     if (!ws) return;
     ws->grids.release(); ws->bbox.release(); ws->cell_of.release(); ws->cell_start.release();
     ws->cursor.release(); ws->counts.release(); ws->scan_scratch.release(); ws->max_count.release();
-    ws->sorted.release();
+    ws->sorted.release(); ws->order.release();
     delete ws;
 }
 
-int ws_radius_neighbors_plan(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
-                             int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
-                             float radius, int32_t* h_max_count, void* stream)
+// bounding boxes, cell grids and the counting sort of the supports (no query work, no sync
+// besides the staging copy of the per-element table)
+static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports, int64_t ns,
+                      const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb, float radius, hipStream_t st)
 {
-    WS_REQUIRE(ws && h_q_lens && h_s_lens && h_max_count, "NULL argument");
+    WS_REQUIRE(ws && h_q_lens && h_s_lens, "NULL argument");
     WS_REQUIRE(nb >= 1 && nq >= 0 && ns >= 0, "bad sizes nb=%d nq=%lld ns=%lld", nb, (long long)nq, (long long)ns);
     WS_REQUIRE(ns < (1ll << 30) && nq < (1ll << 31), "point count exceeds int32 range");
-    *h_max_count = 0;
     ws->max_count_host = 0;
     ws->nq = 0;
-    hipStream_t st = (hipStream_t)stream;
     std::vector<CloudGrid> hg((size_t)nb);
     int64_t qsum = 0, ssum = 0, cells = 0;
     for (int b = 0; b < nb; ++b) {
@@ -339,6 +360,7 @@ int ws_radius_neighbors_plan(ws_neighbors_ws* ws, const float* queries, int64_t 
     if ((rc = ws->scan_scratch.ensure((size_t)ws_scan_scratch_items(cells + 1)))) return rc;
     if ((rc = ws->max_count.ensure(1))) return rc;
     if ((rc = ws->sorted.ensure((size_t)ns))) return rc;
+    if ((rc = ws->order.ensure((size_t)ns))) return rc;
 
     WS_HIP(hipMemcpyAsync(ws->grids.p, hg.data(), sizeof(CloudGrid) * (size_t)nb, hipMemcpyHostToDevice, st));
     WS_HIP(hipStreamSynchronize(st));   // hg is a stack-lifetime staging buffer
@@ -354,17 +376,85 @@ int ws_radius_neighbors_plan(ws_neighbors_ws* ws, const float* queries, int64_t 
     WS_HIP(hipMemcpyAsync(ws->cursor.p, ws->cell_start.p, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToDevice, st));
     nb_bin_fill_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(supports, ns, ws->cell_of.p, ws->cursor.p, ws->sorted.p);
     WS_LAUNCH_CHECK();
-    const float r2 = radius * radius;   // neighbors.cpp:226
-    nb_count_kernel<<<ws_grid(nq, 4), 256, 0, st>>>(queries, nq, ws->grids.p, nb, ws->cell_start.p, ws->sorted.p, r2,
-                                                    ws->counts.p, ws->max_count.p);
+    nb_order_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(ws->sorted.p, ns, ws->order.p);
+    WS_LAUNCH_CHECK();
+    ws->self_query = (queries == supports && nq == ns);
+    ws->queries = queries; ws->nq = nq; ws->ns = ns; ws->nb = nb;
+    ws->r2 = radius * radius;   // neighbors.cpp:226
+    return WS_OK;
+}
+
+int ws_radius_neighbors_plan(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
+                             int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                             float radius, int32_t* h_max_count, void* stream)
+{
+    WS_REQUIRE(h_max_count, "NULL argument");
+    *h_max_count = 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
+    if (rc) { if (ws) ws->nq = 0; return rc; }
+    nb_count_kernel<<<ws_grid(nq, 4), 256, 0, st>>>(queries, nq, ws->grids.p, nb, ws->cell_start.p, ws->sorted.p, ws->r2,
+                                                    ws->self_query ? ws->order.p : nullptr, ws->counts.p, ws->max_count.p);
     WS_LAUNCH_CHECK();
     int32_t mc = 0;
     WS_HIP(hipMemcpyAsync(&mc, ws->max_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     WS_HIP(hipStreamSynchronize(st));
-    ws->queries = queries; ws->nq = nq; ws->ns = ns; ws->nb = nb; ws->r2 = r2; ws->max_count_host = mc;
+    ws->max_count_host = mc;
     *h_max_count = mc;
     if (mc == 0) return ws_fail(WS_ERR_EMPTY, "Error");
     return WS_OK;
+}
+
+static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* out_i32, int64_t* out_i64,
+                          bool with_counts, hipStream_t st)
+{
+    const int grid = ws_grid(ws->nq, 4);
+    const int32_t* qo = ws->self_query ? ws->order.p : nullptr;
+    int32_t* cn = with_counts ? ws->counts.p : nullptr;
+    int32_t* mx = with_counts ? ws->max_count.p : nullptr;
+#define WS_NB_FILL(CAP)                                                                                            \
+    do {                                                                                                           \
+        if (out_i32)                                                                                               \
+            nb_fill_kernel<CAP, int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p, \
+                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i32, cn, mx);  \
+        else                                                                                                       \
+            nb_fill_kernel<CAP, int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p, \
+                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx);  \
+    } while (0)
+    if (cap <= 128) WS_NB_FILL(128);
+    else if (cap <= 512) WS_NB_FILL(512);
+    else if (cap <= 2048) WS_NB_FILL(2048);
+    else return ws_fail(WS_ERR_UNSUPPORTED, "max neighbour count %d exceeds the 2048-entry sort slab", cap);
+#undef WS_NB_FILL
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+int ws_radius_neighbors_search(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
+                               int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                               float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
+                               int32_t* h_max_count, void* stream)
+{
+    WS_REQUIRE(h_max_count, "NULL argument");
+    WS_REQUIRE((out_i32 != nullptr) != (out_i64 != nullptr), "exactly one of out_i32 / out_i64 must be given");
+    WS_REQUIRE(width >= 1, "width must be >= 1");
+    *h_max_count = 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
+    if (rc) { if (ws) ws->nq = 0; return rc; }
+    int cap = 128;
+    for (;;) {
+        WS_HIP(hipMemsetAsync(ws->max_count.p, 0, sizeof(int32_t), st));
+        if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st))) return rc;
+        int32_t mc = 0;
+        WS_HIP(hipMemcpyAsync(&mc, ws->max_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        WS_HIP(hipStreamSynchronize(st));
+        ws->max_count_host = mc;
+        *h_max_count = mc;
+        if (mc == 0) return ws_fail(WS_ERR_EMPTY, "Error");
+        if (mc <= cap) return WS_OK;
+        cap = mc;      // a row overflowed the sort slab: run once more with a slab that fits
+    }
 }
 
 int ws_radius_neighbors_fill(ws_neighbors_ws* ws, int32_t width, int32_t* out_i32, int64_t* out_i64, void* stream)
@@ -372,24 +462,13 @@ int ws_radius_neighbors_fill(ws_neighbors_ws* ws, int32_t width, int32_t* out_i3
     WS_REQUIRE(ws && ws->nq > 0 && ws->max_count_host > 0, "no successful plan to fill from");
     WS_REQUIRE((out_i32 != nullptr) != (out_i64 != nullptr), "exactly one of out_i32 / out_i64 must be given");
     WS_REQUIRE(width >= 1 && width <= ws->max_count_host, "width %d outside [1, max_count=%d]", width, ws->max_count_host);
-    hipStream_t st = (hipStream_t)stream;
-    const int grid = ws_grid(ws->nq, 4);
-    const int mc = ws->max_count_host;
-#define WS_NB_FILL(CAP)                                                                                          \
-    do {                                                                                                         \
-        if (out_i32)                                                                                             \
-            nb_fill_kernel<CAP, int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb,          \
-                                                               ws->cell_start.p, ws->sorted.p, ws->r2, ws->ns, width, out_i32); \
-        else                                                                                                     \
-            nb_fill_kernel<CAP, int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb,          \
-                                                               ws->cell_start.p, ws->sorted.p, ws->r2, ws->ns, width, out_i64); \
-    } while (0)
-    if (mc <= 128) WS_NB_FILL(128);
-    else if (mc <= 512) WS_NB_FILL(512);
-    else if (mc <= 2048) WS_NB_FILL(2048);
-    else return ws_fail(WS_ERR_UNSUPPORTED, "max neighbour count %d exceeds the 2048-entry sort slab", mc);
-#undef WS_NB_FILL
-    WS_LAUNCH_CHECK();
+    return nb_launch_fill(ws, ws->max_count_host, width, out_i32, out_i64, false, (hipStream_t)stream);
+}
+
+int ws_radius_neighbors_order(const ws_neighbors_ws* ws, int32_t* out_order, void* stream)
+{
+    WS_REQUIRE(ws && ws->ns > 0 && out_order, "no plan / NULL argument");
+    WS_HIP(hipMemcpyAsync(out_order, ws->order.p, sizeof(int32_t) * (size_t)ws->ns, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return WS_OK;
 }
 

@@ -43,6 +43,7 @@ static inline int ws_grid(int64_t items, int per_block, int max_blocks = 256 * 1
     int64_t b = ws_ceil_div(items, per_block);
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;
+    if (b > 8) b = (b + 7) / 8 * 8;   // whole rounds over the 8 XCDs (ws_block_range)
     return (int)b;
 }
 
@@ -51,6 +52,20 @@ __device__ __forceinline__ int ws_lane() { return threadIdx.x & 63; }
 __device__ __forceinline__ float ws_readlane_f(float v, int lane)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// Contiguous item range of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs
+// (observed, not contractual -- only speed depends on it): block b and b+8 share an L2.  The remap
+// gives each XCD one contiguous eighth of the (spatially ordered) work list, so that the rows a
+// workgroup gathers were just touched by its neighbours on the same L2.
+__device__ __forceinline__ void ws_block_range(int64_t n_items, int64_t& beg, int64_t& end)
+{
+    const int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
+    const int64_t per = (n_items + nblk - 1) / nblk;
+    beg = (int64_t)b * per;
+    end = beg + per < n_items ? beg + per : n_items;
+    if (beg > n_items) beg = n_items;
 }
 __device__ __forceinline__ float ws_wave_sum(float v)
 {

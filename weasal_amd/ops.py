@@ -93,6 +93,28 @@ def clear_table_cache():
 
 
 # ------------------------------------------------------------------------------------------------
+# scheduling orders: a spatially coherent permutation per point set (the cell order of the
+# neighbour search).  Pure performance hint -- results never depend on it.
+# ------------------------------------------------------------------------------------------------
+_orders = {}
+
+
+def register_point_order(points, order):
+    _orders[points.data_ptr()] = order
+
+
+def clear_point_orders():
+    _orders.clear()
+
+
+def _order_for(points):
+    o = _orders.get(points.data_ptr())
+    if o is not None and o.numel() == points.shape[0] and o.device == points.device:
+        return o
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
 # KPConv gather (K3 / K4 / K6)
 # ------------------------------------------------------------------------------------------------
 class _KPConvGather(torch.autograd.Function):
@@ -114,7 +136,8 @@ class _KPConvGather(torch.autograd.Function):
         tok = _tbegin("kpconv_gather_fwd", nq, h, ci)
         check(lib.ws_kpconv_gather_fwd(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci,
                                        ptr(kernel_points), k, ptr(dkp), ptr(mod), float(extent),
-                                       influence, aggregation, ptr(wf), ptr(min_d2), current_stream()))
+                                       influence, aggregation, ptr(_order_for(q_pts)), ptr(wf), ptr(min_d2),
+                                       current_stream()))
         _tend(tok)
         ctx.save_for_backward(x, dkp, mod, q_pts, s_pts, inds, kernel_points)
         ctx.cfg = (float(extent), influence, aggregation)
@@ -136,7 +159,8 @@ class _KPConvGather(torch.autograd.Function):
             tok = _tbegin("kpconv_gather_bwd_x", nq, h, ci)
             check(lib.ws_kpconv_gather_bwd_x(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(table.offsets),
                                              ptr(table.pairs), ptr(dwf), ci, ptr(kernel_points), k, ptr(dkp),
-                                             ptr(mod), extent, influence, aggregation, ptr(dx), current_stream()))
+                                             ptr(mod), extent, influence, aggregation, ptr(_order_for(s_pts)),
+                                             ptr(dx), current_stream()))
             _tend(tok)
         if dkp is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             d_dkp = torch.empty_like(dkp)
@@ -340,7 +364,7 @@ def _host_lens(lens):
 
 
 def radius_neighbors(queries, supports, q_lens, s_lens, radius, limit=None, dtype=torch.int64,
-                     return_counts=False):
+                     return_counts=False, return_order=False):
     """Batched radius search on device tensors (reference: cpp_neighbors.batch_query,
     neighbors.cpp:211-332).  q_lens/s_lens: host sequences.  Returns [Nq, min(max_count, limit)]
     of `dtype` (int32 like the reference module, or int64 like datasets/common.py:551 makes it)."""
@@ -354,23 +378,36 @@ def radius_neighbors(queries, supports, q_lens, s_lens, radius, limit=None, dtyp
         raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
     ws = _ws.neighbors(q.device)
     mc = C.c_int32(0)
+    hq, hs = C.c_void_p(ql.ctypes.data), C.c_void_p(sl.ctypes.data)
+    if dtype not in (torch.int32, torch.int64):
+        raise ValueError("dtype must be torch.int32 or torch.int64")
     with torch.cuda.device(q.device):
-        check(lib.ws_radius_neighbors_plan(ws, ptr(q), q.shape[0], ptr(s), s.shape[0],
-                                           C.c_void_p(ql.ctypes.data), C.c_void_p(sl.ctypes.data), ql.shape[0],
-                                           float(np.float32(radius)), C.byref(mc), current_stream()))
-        width = mc.value if limit is None else max(1, min(mc.value, int(limit)))
-        out = torch.empty((q.shape[0], width), dtype=dtype, device=q.device)
-        if dtype == torch.int32:
-            check(lib.ws_radius_neighbors_fill(ws, width, ptr(out), None, current_stream()))
-        elif dtype == torch.int64:
-            check(lib.ws_radius_neighbors_fill(ws, width, None, ptr(out), current_stream()))
+        if limit is not None:
+            # one query pass: write `limit` columns and count together; trim if the true width is smaller
+            width = max(1, int(limit))
+            out = torch.empty((q.shape[0], width), dtype=dtype, device=q.device)
+            o32, o64 = (ptr(out), None) if dtype == torch.int32 else (None, ptr(out))
+            check(lib.ws_radius_neighbors_search(ws, ptr(q), q.shape[0], ptr(s), s.shape[0], hq, hs, ql.shape[0],
+                                                 float(np.float32(radius)), width, o32, o64, C.byref(mc),
+                                                 current_stream()))
+            if mc.value < width:
+                out = out[:, :mc.value].contiguous()
         else:
-            raise ValueError("dtype must be torch.int32 or torch.int64")
+            check(lib.ws_radius_neighbors_plan(ws, ptr(q), q.shape[0], ptr(s), s.shape[0], hq, hs, ql.shape[0],
+                                               float(np.float32(radius)), C.byref(mc), current_stream()))
+            width = mc.value
+            out = torch.empty((q.shape[0], width), dtype=dtype, device=q.device)
+            o32, o64 = (ptr(out), None) if dtype == torch.int32 else (None, ptr(out))
+            check(lib.ws_radius_neighbors_fill(ws, width, o32, o64, current_stream()))
+        res = [out]
         if return_counts:
-            counts = torch.as_tensor(_DevView(lib.ws_radius_neighbors_counts(ws), q.shape[0]),
-                                     device=q.device).clone()
-            return out, counts
-    return out
+            res.append(torch.as_tensor(_DevView(lib.ws_radius_neighbors_counts(ws), q.shape[0]),
+                                       device=q.device).clone())
+        if return_order:
+            order = torch.empty(s.shape[0], dtype=torch.int32, device=q.device)
+            check(lib.ws_radius_neighbors_order(ws, ptr(order), current_stream()))
+            res.append(order)
+    return res[0] if len(res) == 1 else tuple(res)
 
 
 def grid_subsample(points, lens, dl, max_p=0, features=None, labels=None, reference_order=True,

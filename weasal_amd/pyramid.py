@@ -20,9 +20,15 @@ from . import ops
 from .kernel_points import create_3D_rotations
 
 
-def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None):
-    """device form of datasets/common.py:185-196 (+ the crop of :336-346 and the int64 cast of :551)"""
-    return ops.radius_neighbors(queries, supports, q_batches, s_batches, radius, limit=limit, dtype=torch.int64)
+def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None, register_order=False):
+    """device form of datasets/common.py:185-196 (+ the crop of :336-346 and the int64 cast of :551).
+    register_order: remember the supports' cell order as the scheduling order of that point set."""
+    if not register_order:
+        return ops.radius_neighbors(queries, supports, q_batches, s_batches, radius, limit=limit, dtype=torch.int64)
+    inds, order = ops.radius_neighbors(queries, supports, q_batches, s_batches, radius, limit=limit,
+                                       dtype=torch.int64, return_order=True)
+    ops.register_point_order(supports, order)
+    return inds
 
 
 def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_grid_orient=True):
@@ -50,6 +56,8 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
     """-> flat list  points[L] + neighbors[L] + pools[L] + upsamples[L] + lengths[L] + [features, labels]
     (datasets/common.py:574-575), all device tensors (lengths int32, indices int64)."""
     dev = stacked_points.device
+    stacked_points = stacked_points.detach().to(torch.float32).contiguous()
+    ops.clear_point_orders()
     lens = np.asarray(stack_lengths.cpu() if isinstance(stack_lengths, torch.Tensor) else stack_lengths, dtype=np.int32)
     r_normal = config.first_subsampling_dl * config.conv_radius
     limits = list(neighborhood_limits)
@@ -70,7 +78,7 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
                 r = r_normal * config.deform_radius / config.conv_radius
             else:
                 r = r_normal
-            conv_i = batch_neighbors(stacked_points, stacked_points, lens, lens, r, limit(layer))
+            conv_i = batch_neighbors(stacked_points, stacked_points, lens, lens, r, limit(layer), register_order=True)
         else:
             conv_i = empty_i()
         if 'pool' in block or 'strided' in block:
