@@ -206,22 +206,35 @@ __global__ __launch_bounds__(256) void gemm_xty_kernel(const float* __restrict__
     }
 }
 
-// out[e] = sum_c partial[c][e], chunks in a fixed order (bitwise reproducible)
+// out[e] = sum_c partial[c][e] in a fixed order (bitwise reproducible): 32 elements x 8 chunk groups
+// per workgroup, group g adds chunks g, g+8, ... (coalesced 128-byte reads), then the 8 group sums
+// are added in order.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int64_t elems, int chunks,
                                                                float* __restrict__ out)
 {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < elems; e += (int64_t)gridDim.x * 256) {
-        float s = 0.0f;
-        for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * elems + e];
-        out[e] = s;
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + el;
+    float s = 0.0f;
+    if (e < elems)
+        for (int c = grp; c < chunks; c += 8) s += partial[(int64_t)c * elems + e];
+    red[grp][el] = s;
+    __syncthreads();
+    if (grp == 0 && e < elems) {
+        float t = red[0][el];
+#pragma unroll
+        for (int g2 = 1; g2 < 8; ++g2) t += red[g2][el];
+        out[e] = t;
     }
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int64_t xty_chunk(int64_t m)
+int64_t xty_chunk(int64_t m, int k, int n)
 {
-    // <= 256 chunks, a multiple of BK rows each, at least 512 rows
+    (void)k; (void)n;
+    // <= 256 chunks, a multiple of BK rows each, at least 512 rows (keeps >= 256 workgroups in
+    // flight for the tall layers even when K fits one k-tile)
     int64_t c = ws_ceil_div(m, 256);
     if (c < 512) c = 512;
     return ws_ceil_div(c, BK) * BK;
@@ -256,7 +269,7 @@ int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b
 
 int64_t ws_gemm_xty_scratch_bytes(int64_t m, int32_t k, int32_t n)
 {
-    const int64_t chunk = xty_chunk(m);
+    const int64_t chunk = xty_chunk(m, k, n);
     return ws_ceil_div(m > 0 ? m : 1, chunk) * (int64_t)k * n * (int64_t)sizeof(float);
 }
 
@@ -271,7 +284,7 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
         return WS_OK;
     }
     WS_REQUIRE(x && y && scratch, "NULL argument");
-    const int64_t chunk = xty_chunk(m);
+    const int64_t chunk = xty_chunk(m, k, n);
     const int chunks = (int)ws_ceil_div(m, chunk);
     const int vecx = al16(x) && (ldx % 4 == 0);
     const int vecy = al16(y) && (ldy % 4 == 0);
@@ -288,7 +301,7 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
     WS_LAUNCH_CHECK();
     if (chunks > 1) {
         const int64_t elems = (int64_t)k * n;
-        reduce_partials_kernel<<<ws_grid(elems, 256), 256, 0, st>>>(partial, elems, chunks, out);
+        reduce_partials_kernel<<<(unsigned)ws_ceil_div(elems, 32), 256, 0, st>>>(partial, elems, chunks, out);
         WS_LAUNCH_CHECK();
     }
     return WS_OK;

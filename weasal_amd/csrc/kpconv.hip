@@ -1,19 +1,14 @@
-// weasal_amd/csrc/kpconv.hip -- fused KPConv gather kernels for gfx950 (wave64, LDS-staged rows).
+// weasal_amd/csrc/kpconv.hip -- fused KPConv gather kernels for gfx950 (wave64).
 //
 // Reference semantics: models/blocks.py:238-374 (KPConv.forward) and its autograd.
 //
 // K3  kpconv_gather_fwd :  wf[q,k,c] = sum_h w(q,h,k) * x[inds[q,h], c]
-//     One wave owns one query at a time.  Phase 1: lane = neighbour column; each lane loads its
-//     index and neighbour xyz and evaluates the K kernel-point influences in registers.  Phase 2:
-//     the feature rows of the neighbours that have any influence are staged in the wave's LDS
-//     slab with 16-byte accesses (a row is contiguous in HBM, 4*ci bytes).  Phase 3: lane =
-//     (entry slot, channel); for every kernel point the non-zero influences are enumerated from a
-//     wave ballot (ctz over the mask, weights broadcast by v_readlane) and accumulated from LDS.
-//     The [N,H,K,3] / [N,H,K] / [N,H,Ci] intermediates of the reference never exist.
-//     With `linear` influence only ~1 of the 15 kernel points is non-zero per neighbour, so the
-//     accumulate runs over the sparse entries instead of the dense 15 x H matrix.
+//     neighbour gather -> kernel-point influence -> feature aggregate in ONE kernel; the
+//     [N,H,3] / [N,H,K,3] / [N,H,K] / [N,H,Ci] intermediates of the reference never exist.
 // K4  kpconv_gather_bwd_x : dx[s,c] = sum_{(q,h)->s} sum_k w * dwf[q,k,c]   (transposed table, no atomics)
 // K6  kpconv_gather_bwd_geom : d deformed_kp, d modulations (deformable only)
+// The structure of K3/K4 (entry pool in LDS, branch-free flush, scheduling order) is described
+// above the kernels.
 #include "ws_common.h"
 
 namespace {

@@ -6,7 +6,57 @@
 
 namespace {
 
-// one wave per query row; lanes stride over channels
+__device__ __forceinline__ int64_t ws_ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// VEC path (c % 4 == 0, 16-byte aligned rows): G = c/4 lanes (capped at 64) cover one row with
+// float4 pieces, 64/G query rows per wave, the neighbour loop unrolled by 4 so that four row
+// gathers are in flight per lane; shadow columns read nothing (zero row, blocks.py:104).
+template <int G>
+__global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const float* __restrict__ x, int64_t ns, int c,
+                                                                const int64_t* __restrict__ inds, int64_t nq, int h,
+                                                                float* __restrict__ out, int32_t* __restrict__ arg)
+{
+    constexpr int S = 64 / G;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = lane % G, slot = lane / G;
+    int64_t ibeg, iend;
+    ws_block_range(ws_ceil_div_dev(nq, S), ibeg, iend);
+    for (int64_t grp = ibeg + wave; grp < iend; grp += 4) {
+        const int64_t q = grp * S + slot;
+        const bool qok = q < nq;
+        for (int c0 = 0; c0 < c; c0 += 4 * G) {
+            const int ch = c0 + 4 * j;
+            const bool ok = qok && ch < c;
+            float4 best = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+            int bi[4] = {0, 0, 0, 0};
+            for (int h0 = 0; h0 < h; h0 += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int col = h0 + u;
+                    int64_t s = (ok && col < h) ? inds[q * h + col] : -1;
+                    if (s >= 0 && s < ns) v[u] = *reinterpret_cast<const float4*>(x + s * c + ch);
+                    else if (col >= h) v[u] = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {               // first maximum wins
+                    if (v[u].x > best.x) { best.x = v[u].x; bi[0] = h0 + u; }
+                    if (v[u].y > best.y) { best.y = v[u].y; bi[1] = h0 + u; }
+                    if (v[u].z > best.z) { best.z = v[u].z; bi[2] = h0 + u; }
+                    if (v[u].w > best.w) { best.w = v[u].w; bi[3] = h0 + u; }
+                }
+            }
+            if (ok) {
+                *reinterpret_cast<float4*>(out + q * c + ch) = best;
+                if (arg) *reinterpret_cast<int4*>(arg + q * c + ch) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+            }
+        }
+    }
+}
+
+// generic path: one wave per query row; lanes stride over channels
 __global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float* __restrict__ x, int64_t ns, int c,
                                                             const int64_t* __restrict__ inds, int64_t nq, int h,
                                                             float* __restrict__ out, int32_t* __restrict__ arg)
@@ -27,6 +77,41 @@ __global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float* __restri
                 out[q * c + ch] = best;
                 if (arg) arg[q * c + ch] = bi;
             }
+        }
+    }
+}
+
+// backward, VEC path: G lanes x float4 per support row, 64/G supports per wave
+template <int G>
+__global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg,
+                                                                int h, int c, const int32_t* __restrict__ t_offsets,
+                                                                const int32_t* __restrict__ t_pairs, int64_t ns,
+                                                                float* __restrict__ dx)
+{
+    constexpr int S = 64 / G;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = lane % G, slot = lane / G;
+    int64_t ibeg, iend;
+    ws_block_range(ws_ceil_div_dev(ns, S), ibeg, iend);
+    for (int64_t grp = ibeg + wave; grp < iend; grp += 4) {
+        const int64_t s = grp * S + slot;
+        const bool sok = s < ns;
+        const int beg = sok ? t_offsets[s] : 0, end = sok ? t_offsets[s + 1] : 0;
+        for (int c0 = 0; c0 < c; c0 += 4 * G) {
+            const int ch = c0 + 4 * j;
+            if (!(sok && ch < c)) continue;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = beg; p < end; ++p) {
+                const int pair = t_pairs[p];
+                const int q = pair / h, col = pair - q * h;
+                const int4 a = *reinterpret_cast<const int4*>(arg + (int64_t)q * c + ch);
+                const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)q * c + ch);
+                if (a.x == col) acc.x += g.x;
+                if (a.y == col) acc.y += g.y;
+                if (a.z == col) acc.z += g.z;
+                if (a.w == col) acc.w += g.w;
+            }
+            *reinterpret_cast<float4*>(dx + s * c + ch) = acc;
         }
     }
 }
@@ -100,7 +185,14 @@ int ws_max_pool_fwd(const float* x, int64_t ns, int32_t c, const int64_t* inds, 
     WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
     if (nq == 0) return WS_OK;
     WS_REQUIRE(inds && out && (ns == 0 || x), "NULL argument");
-    max_pool_fwd_kernel<<<ws_grid(nq, 4), 256, 0, (hipStream_t)stream>>>(x, ns, c, inds, nq, h, out, arg);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && al16p(x) && al16p(out) && (!arg || al16p(arg));
+    if (vec && c <= 16) max_pool_fwd_vec_kernel<4><<<ws_grid(ws_ceil_div(nq, 16), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (vec && c <= 32) max_pool_fwd_vec_kernel<8><<<ws_grid(ws_ceil_div(nq, 8), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (vec && c <= 64) max_pool_fwd_vec_kernel<16><<<ws_grid(ws_ceil_div(nq, 4), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (vec && c <= 128) max_pool_fwd_vec_kernel<32><<<ws_grid(ws_ceil_div(nq, 2), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (vec) max_pool_fwd_vec_kernel<64><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else max_pool_fwd_kernel<<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
@@ -111,7 +203,13 @@ int ws_max_pool_bwd(const float* dy, const int32_t* arg, int64_t nq, int32_t h, 
     WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
     if (ns == 0) return WS_OK;
     WS_REQUIRE(t_offsets && dx && (nq == 0 || (dy && arg && t_pairs)), "NULL argument");
-    max_pool_bwd_kernel<<<ws_grid(ns, 4), 256, 0, (hipStream_t)stream>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && al16p(dy) && al16p(dx) && al16p(arg);
+    if (vec && c <= 32) max_pool_bwd_vec_kernel<8><<<ws_grid(ws_ceil_div(ns, 8), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else if (vec && c <= 64) max_pool_bwd_vec_kernel<16><<<ws_grid(ws_ceil_div(ns, 4), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else if (vec && c <= 128) max_pool_bwd_vec_kernel<32><<<ws_grid(ws_ceil_div(ns, 2), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else if (vec) max_pool_bwd_vec_kernel<64><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else max_pool_bwd_kernel<<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
