@@ -70,20 +70,32 @@ __device__ __forceinline__ void wave_lds_sync()
 // ---------------------------------------------------------------------------------------------
 // Pool + accumulate structure shared by K3 (forward) and K4 (backward w.r.t. x).
 //
-// One wave owns one query (K3) / one support (K4) at a time and works in two alternating phases:
-//   list phase   lane = neighbour column (K3) or incoming pair (K4).  For each kernel point the
-//                influence is evaluated in registers (nothing is kept per kernel point), the
-//                non-zero ones are compacted by ballot + mbcnt into the wave's LDS entry pool as
-//                (row | k, weight).  With `linear` influence ~1 of the 15 kernel points is
-//                non-zero per neighbour, so the pool holds ~H entries instead of 15*H.
-//   flush phase  lane = (entry slot, 16-byte piece of the row): G lanes read one feature row
-//                segment as float4 (a row is 4*ci contiguous bytes -> 64..256-byte coalesced
-//                segments straight from L2/HBM, no staging copy), S = 64/G entries per step.
-//                K3 adds w * x into the wave's LDS accumulator wf[k][c] (ds_add_f32, order fixed
-//                by lane and instruction order -> deterministic); K4 adds into registers.
-// The pool is flushed whenever it could overflow, so any H / any influence mode fits.
+// One wave owns one query (K3) / one support (K4) at a time and alternates two phases:
+//   list phase   lane = neighbour column (K3) or incoming pair (K4).  The influence of each kernel
+//                point is evaluated in registers and the non-zero ones are compacted (v_cmp mask +
+//                mbcnt rank) into the wave's LDS entry pool as (row, weight), kernel point after
+//                kernel point, so the pool is grouped by kernel point (segs[k] = start of k).
+//                With `linear` influence ~1 of the 15 kernel points is non-zero per neighbour: the
+//                pool holds ~H entries instead of 15*H.
+//   flush phase  lane = (entry slot, 16-byte piece of the row): G lanes read one feature-row
+//                segment as float4 straight from L2/HBM (a row is 4*ci contiguous bytes -> 64..256
+//                byte coalesced segments, no staging copy), S = 64/G entries per step, register
+//                accumulation, no atomics (LDS float atomics were measured at ~1 lane/clk on gfx950).
+//
+// What bounds these kernels is the scalar unit (one SALU per CU) and divergent-branch bookkeeping,
+// not HBM: profiles/r01 showed ~520 SALU instructions per query.  Hence
+//   * MODE 0 (rigid kernel, linear influence, sum aggregation -- every shipped configuration) is a
+//     separate instantiation: no per-kernel-point mode dispatch, the 15 kernel points live in SGPRs
+//     for the whole launch, the list phase is fully unrolled;
+//   * pool writes are unconditional (lanes without an entry write to a private dummy slot) and the
+//     flush loops are branch free (lanes past the end of their segment carry weight 0 and read
+//     row 0), so no exec-mask save/restore sits in any inner loop;
+//   * pool overflow (only possible with dense influence modes or collapsed deformed kernels) is
+//     handled after the fact: the chunk is redone in four 16-lane sub-chunks that always fit.
+// MODE 1 keeps every influence / aggregation / deformable combination behind runtime switches.
 // ---------------------------------------------------------------------------------------------
-constexpr int POOL = 320;   // entries per wave (8 B each); must be >= 128
+constexpr int POOL = 256;                 // real entries per wave (8 B each), >= 16 * 15
+constexpr int POOL_ALLOC = POOL + 8 + 64;  // + read-past slack of the flush + one dummy slot per lane
 
 __device__ __forceinline__ int lane_rank(unsigned long long m)
 {
@@ -99,19 +111,14 @@ __device__ __forceinline__ float kp_weight(float d2, const GeomParams& g, float 
     return __expf(-d2 / (2.0f * sig * sig + 1e-9f));
 }
 
-__device__ __forceinline__ float kp_d2(float nx, float ny, float nz, const float* __restrict__ kp, int k)
-{
-    const float dx = nx - kp[3 * k + 0], dy = ny - kp[3 * k + 1], dz = nz - kp[3 * k + 2];
-    return (dx * dx + dy * dy) + dz * dz;
-}
-
 // 16-byte piece of a feature row, branch free.  VEC: the caller guarantees ch+3 < ci (or passes
 // ch = 0 together with a zero weight).  !VEC: element-wise with clamped columns; columns >= ci
 // are zeroed.
 template <bool VEC>
-__device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base, int64_t row, int ci, int ch)
+__device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base, unsigned row, int ci, int ch)
 {
-    const float* src = base + row * ci;
+    // 32-bit element offset (the launcher checks rows * ci < 2^31): one v_mul_lo_u32 + one 64-bit add
+    const float* src = base + (size_t)(row * (unsigned)ci);
     if (VEC) return *reinterpret_cast<const float4*>(src + ch);
     float4 v;
     const int last = ci - 1;
@@ -123,19 +130,87 @@ __device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base,
     return v;
 }
 
-// K3 forward.  The list phase appends kernel point after kernel point, so the pool is grouped by
-// kernel point; segs[k] marks where k starts.  In the flush phase entry slot s owns the kernel
-// points s, s+S, s+2S, ...: it walks their segments with a float4 register accumulator and stores
-// the finished 16-byte piece of wf[q,k,:] straight to HBM.  No atomics, fixed summation order.
-// (LDS float atomics were measured at ~1 lane/clk on gfx950 -- 3x slower end to end.)
-// The pool (256 entries, ~4x the typical load of a 64-column chunk) is built once per column chunk
-// and flushed for every 4*G-channel chunk; if it would overflow (dense influence modes, collapsed
-// deformed kernels) the finished segments are flushed early and later flushes accumulate onto the
-// rows already written, as do further column chunks (H > 64).
-// The kernel is latency bound (index -> neighbour xyz -> feature rows are dependent gathers), so
-// the index and xyz loads of the next two items are software-prefetched under the current item.
-constexpr int FPOOL = 256;
-template <int K, int G, bool DEF, bool VEC>
+// keeps a pool read unconditional: without it the compiler sinks `ok ? pool[i] : 0` back under an
+// exec-mask branch (s_and_saveexec + s_cbranch per entry -- the scalar unit is the bottleneck here)
+__device__ __forceinline__ void keep_unconditional(uint2& e) { asm volatile("" : "+v"(e.x), "+v"(e.y)); }
+
+// List phase for one 64-lane chunk.  KPF: kp(k, c) -> coordinate c of kernel point k (SGPR array,
+// wave-uniform pointer or per-lane pointer).  Entry row = row_base + k * row_step.
+// MINF: optional per-kernel-point hook (k, d2) used by the deformable forward for min_d2.
+template <int K, int MODE, typename KPF, typename MINF>
+__device__ __forceinline__ void kp_list(float nx, float ny, float nz, bool live, KPF kp, const GeomParams& g,
+                                        float inv_extent, unsigned row_base, unsigned row_step, const float* __restrict__ lane_mod,
+                                        uint2* pool, int* segs, int lane, int& total, int& maxlen, MINF minf)
+{
+    const unsigned dummy = POOL + 8 + lane;
+    auto emit = [&](int k, float w) {
+        const unsigned long long m = __ballot(w != 0.0f);
+        const unsigned pos = (unsigned)(total + lane_rank(m));
+        const bool ok = (w != 0.0f) && pos < (unsigned)POOL;
+        pool[ok ? pos : dummy] = make_uint2(row_base + (unsigned)k * row_step, __float_as_uint(w));
+        segs[k] = total;                                   // every lane, same value
+        const int c = __builtin_popcountll(m);
+        total += c;
+        maxlen = max(maxlen, c);
+    };
+    if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float dx = nx - kp(k, 0), dy = ny - kp(k, 1), dz = nz - kp(k, 2);
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d) * inv_extent, 0.0f);
+            w = live ? w : 0.0f;
+            emit(k, w);
+        }
+    } else {
+        constexpr int KU = 3;
+        static_assert(K % KU == 0, "K must be a multiple of 3");
+        const float e2 = g.extent * g.extent;
+        int arg = 0;
+        if (g.deformable || g.aggregation == WS_AGGREGATION_CLOSEST) {
+            float best = 3.4e38f;
+            bool inrange = false;
+#pragma unroll 1
+            for (int kb = 0; kb < K; kb += KU) {
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    const int k = kb + u;
+                    const float dx = nx - kp(k, 0), dy = ny - kp(k, 1), dz = nz - kp(k, 2);
+                    const float d = (dx * dx + dy * dy) + dz * dz;
+                    if (d < best) { best = d; arg = k; }
+                    inrange |= d < e2;
+                }
+            }
+            if (g.deformable) live = live && inrange;
+        }
+#pragma unroll 1
+        for (int kb = 0; kb < K; kb += KU) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int k = kb + u;
+                const float dx = nx - kp(k, 0), dy = ny - kp(k, 1), dz = nz - kp(k, 2);
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                minf(k, d);
+                float w = kp_weight(d, g, inv_extent);
+                if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
+                w = live ? w : 0.0f;
+                if (lane_mod && w != 0.0f) w *= lane_mod[k];
+                emit(k, w);
+            }
+        }
+    }
+    segs[K] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 forward.  In the flush phase entry slot s owns the kernel points s, s+S, s+2S, ...: it walks
+// their segments with a float4 register accumulator and stores the finished 16-byte piece of
+// wf[q,k,:] straight to HBM (fixed summation order).  The pool is built once per 64-column chunk
+// and flushed for every 4*G-channel chunk; further column chunks (H > 64) and overflow sub-chunks
+// accumulate onto the rows already written.  The index and xyz loads of the next two items are
+// software-prefetched under the current item.
+// ---------------------------------------------------------------------------------------------
+template <int K, int G, int MODE, bool DEF, bool VEC>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
@@ -143,12 +218,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float* __restrict__ modulations, GeomParams g, float* __restrict__ wf,
     float* __restrict__ min_d2, const int32_t* __restrict__ order)
 {
+    static_assert(!(DEF && MODE == 0), "deformable layers use MODE 1");
     constexpr int CC = 4 * G;      // channels per chunk
     constexpr int S = 64 / G;      // entry slots
     constexpr int KPS = (K + S - 1) / S;   // kernel points per slot
-    constexpr int KU = 3;          // kernel points per list-phase trip (K % KU == 0)
-    static_assert(K % KU == 0 && K <= 16 && FPOOL >= 64 * KU + 64, "pool sizing");
-    __shared__ uint2 pool_all[4][FPOOL + 8];   // +8: the branch-free flush may read (and ignore) past the end
+    static_assert(K <= 16 && POOL >= 16 * K, "pool sizing");
+    __shared__ uint2 pool_all[4][POOL_ALLOC];
     __shared__ int segs_all[4][K + 1];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -157,15 +232,19 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const int j = lane % G;        // 16-byte piece of the row chunk
     const int slot = lane / G;
     const float inv_extent = 1.0f / g.extent;
-    const float e2 = g.extent * g.extent;
-    const bool need_pre = DEF || g.aggregation == WS_AGGREGATION_CLOSEST;
 
     int64_t ibeg, iend;
     ws_block_range(nq, ibeg, iend);
 
+    // MODE 0: the rigid kernel points are wave-uniform for the whole launch -> registers (SGPRs)
+    float kpr[MODE == 0 ? 3 * K : 1];
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 3 * K; ++t) kpr[t] = kernel_points[t];
+    }
+
     // flush the pool: every slot walks the segments of its kernel points for all channel chunks.
-    // maxlen = longest segment (wave-uniform): every round runs that many steps, lanes past the end
-    // of their own segment carry weight 0 and read row 0 -- no divergent branches in the loop.
+    // maxlen = longest segment (wave-uniform): every round runs that many steps.
     auto flush = [&](int64_t q, bool accumulate, int maxlen) {
         wave_lds_sync();
         for (int cc0 = 0; cc0 < ci; cc0 += CC) {
@@ -177,18 +256,22 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
                 const int k = slot + kk * S;
                 const bool kok = k < K && chok;
                 const int beg = kok ? segs[k] : 0;
-                const int end = kok ? segs[k + 1] : 0;
+                const int end = kok ? min(segs[k + 1], POOL) : 0;
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int it = 0; it < maxlen; it += 4) {
                     uint2 e[4];
                     float4 v[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        e[u] = pool[beg + it + u];
+                        e[u] = pool[min(beg + it + u, POOL + 7)];
+                        keep_unconditional(e[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
                         const bool ok = beg + it + u < end;
                         e[u].x = ok ? e[u].x : 0u;
                         e[u].y = ok ? e[u].y : 0u;                    // weight 0.0f
-                        v[u] = load_row_piece<VEC>(x, (int64_t)e[u].x, ci, chl);
+                        v[u] = load_row_piece<VEC>(x, e[u].x, ci, chl);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -234,17 +317,16 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
 
     for (int64_t item = ibeg + wave; item < iend; item += 4) {
         const int64_t q = q0;
-        // prefetch: idx of item+8, xyz of item+4
         const int64_t q2 = item_q(item + 8);
         const int idx2 = load_idx(q2);
         float p1x, p1y, p1z;
         load_pt(idx1, p1x, p1y, p1z);
 
         const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
-        const float* kp = DEF ? deformed_kp + q * (3 * K) : kernel_points;
+        const float* kpp = DEF ? deformed_kp + q * (3 * K) : kernel_points;      // wave-uniform
+        auto kp = [&](int k, int c) { return MODE == 0 ? kpr[MODE == 0 ? 3 * k + c : 0] : kpp[3 * k + c]; };
         bool accumulate = false;
         for (int h0 = 0; h0 < h; h0 += 64) {
-            // ---- list phase: lane = neighbour column
             const int col = h0 + lane;
             const bool incol = col < h;
             int idx = idx0;
@@ -256,59 +338,31 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
             }
             const bool real = incol && idx >= 0;
             const float nx = px - qx, ny = py - qy, nz = pz - qz;
-            bool live = real;
-            int arg = 0;
-            if (need_pre) {
-                float best = 3.4e38f;
-                bool inrange = false;
-#pragma unroll 1
-                for (int kb = 0; kb < K; kb += KU) {
-#pragma unroll
-                    for (int u = 0; u < KU; ++u) {
-                        const float d = kp_d2(nx, ny, nz, kp, kb + u);
-                        if (d < best) { best = d; arg = kb + u; }
-                        inrange |= d < e2;
-                    }
-                }
-                if (DEF) live = live && inrange;
-            }
             const unsigned row = (unsigned)(real ? idx : 0);
+            auto minf = [&](int k, float d) {
+                if (DEF && min_d2) {
+                    float m = incol ? d : 3.4e38f;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+                    if (lane == 0) min_d2[q * K + k] = h0 == 0 ? m : fminf(min_d2[q * K + k], m);
+                }
+            };
             int total = 0, maxlen = 0;
-#pragma unroll 1
-            for (int kb = 0; kb < K; kb += KU) {
-                if (total + 64 * KU > FPOOL) {
-                    // early flush of the finished segments; the rest of this chunk accumulates
-                    for (int k2 = kb; k2 <= K; ++k2) segs[k2] = total;
+            kp_list<K, MODE>(nx, ny, nz, real, kp, g, inv_extent, row, 0u, nullptr, pool, segs, lane, total, maxlen, minf);
+            if (total <= POOL) {
+                flush(q, accumulate, maxlen);
+                accumulate = true;
+            } else {
+                // the chunk does not fit the pool: redo it in four 16-lane sub-chunks (16 * K <= POOL)
+                auto nomin = [&](int, float) {};
+                for (int sub = 0; sub < 4; ++sub) {
+                    total = 0; maxlen = 0;
+                    kp_list<K, MODE>(nx, ny, nz, real && (lane >> 4) == sub, kp, g, inv_extent, row, 0u, nullptr, pool, segs,
+                                     lane, total, maxlen, nomin);
                     flush(q, accumulate, maxlen);
                     accumulate = true;
-                    for (int k2 = 0; k2 < kb; ++k2) segs[k2] = 0;
-                    total = 0; maxlen = 0;
-                }
-#pragma unroll
-                for (int u = 0; u < KU; ++u) {
-                    const int k = kb + u;
-                    const float d = kp_d2(nx, ny, nz, kp, k);
-                    if (DEF) {
-                        float m = incol ? d : 3.4e38f;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-                        if (lane == 0 && min_d2) min_d2[q * K + k] = h0 == 0 ? m : fminf(min_d2[q * K + k], m);
-                    }
-                    float w = kp_weight(d, g, inv_extent);
-                    if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
-                    if (!live) w = 0.0f;
-                    const bool nzw = w != 0.0f;
-                    const unsigned long long m = __ballot(nzw);
-                    segs[k] = total;                                   // every lane, same value
-                    if (nzw) pool[total + lane_rank(m)] = make_uint2(row, __float_as_uint(w));
-                    const int c = __builtin_popcountll(m);
-                    total += c;
-                    maxlen = max(maxlen, c);
                 }
             }
-            segs[K] = total;
-            flush(q, accumulate, maxlen);
-            accumulate = true;
         }
         // rotate the pipeline
         q0 = q1; q1 = q2;
@@ -319,8 +373,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // K4 backward w.r.t. x through the transposed table: dx[s, :] = sum_e weight_e * dwf[row_e, :]
+// with row_e = q*K + k.  One wave per support; the flush is balanced over the S slots
+// (slot s takes entries [s*per, (s+1)*per)) and the S partial sums are combined by shuffles.
 // ---------------------------------------------------------------------------------------------
-template <int K, int G, bool VEC>
+template <int K, int G, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     int h, const int32_t* __restrict__ t_offsets, const int32_t* __restrict__ t_pairs,
@@ -330,17 +386,22 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
 {
     constexpr int CC = 4 * G;
     constexpr int S = 64 / G;
-    constexpr int KU = 3;
-    static_assert(K % KU == 0 && POOL >= 64 * KU + 64, "pool sizing");
-    __shared__ uint2 pool_all[4][POOL + 8];
+    static_assert(K <= 16 && POOL >= 16 * K, "pool sizing");
+    __shared__ uint2 pool_all[4][POOL_ALLOC];
+    __shared__ int segs_all[4][K + 1];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     uint2* pool = pool_all[wave];
+    int* segs = segs_all[wave];
     const int j = lane % G;
     const int slot = lane / G;
     const float inv_extent = 1.0f / g.extent;
-    const float e2 = g.extent * g.extent;
-    const bool need_pre = g.deformable || g.aggregation == WS_AGGREGATION_CLOSEST;
+
+    float kpr[MODE == 0 ? 3 * K : 1];
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 3 * K; ++t) kpr[t] = kernel_points[t];
+    }
 
     int64_t ibeg, iend;
     ws_block_range(ns, ibeg, iend);
@@ -353,24 +414,27 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
             const int ch = cc0 + 4 * j;
             const bool chok = VEC ? (ch + 3 < ci) : (ch < ci);
             const int chl = chok ? ch : 0;
-            // balanced, branch-free flush: slot s takes entries [s*per, (s+1)*per); entries past the
-            // end carry weight 0 and read row 0
             auto flush = [&](int total) {
                 wave_lds_sync();
+                total = min(total, POOL);
                 const int per = (total + S - 1) / S;
                 const int lo = slot * per;
                 const int hi = chok ? min(lo + per, total) : lo;
                 for (int it = 0; it < per; it += 4) {
                     float4 v[4];
                     float w[4];
+                    uint2 e[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int idx = min(lo + it + u, POOL + 7);
-                        uint2 e = pool[idx];
+                        e[u] = pool[min(lo + it + u, POOL + 7)];
+                        keep_unconditional(e[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
                         const bool ok = lo + it + u < hi;
-                        e.x = ok ? e.x : 0u;
-                        w[u] = ok ? __uint_as_float(e.y) : 0.0f;
-                        v[u] = load_row_piece<VEC>(dwf, (int64_t)e.x, ci, chl);
+                        e[u].x = ok ? e[u].x : 0u;
+                        w[u] = ok ? __uint_as_float(e[u].y) : 0.0f;
+                        v[u] = load_row_piece<VEC>(dwf, e[u].x, ci, chl);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -382,7 +446,6 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
                 }
                 wave_lds_sync();
             };
-            int total = 0;
             for (int p0 = beg; p0 < end; p0 += 64) {
                 const int p = p0 + lane;
                 const bool real = p < end;
@@ -391,42 +454,24 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
                 const float nx = sx - q_pts[3 * (int64_t)q + 0];
                 const float ny = sy - q_pts[3 * (int64_t)q + 1];
                 const float nz = sz - q_pts[3 * (int64_t)q + 2];
-                const float* kp = deformed_kp ? deformed_kp + (int64_t)q * (3 * K) : kernel_points;   // per lane if deformed
-                bool live = real;
-                int arg = 0;
-                if (need_pre) {
-                    float best = 3.4e38f;
-                    bool inrange = false;
-#pragma unroll 1
-                    for (int kb = 0; kb < K; kb += KU) {
-#pragma unroll
-                        for (int u = 0; u < KU; ++u) {
-                            const float d = kp_d2(nx, ny, nz, kp, kb + u);
-                            if (d < best) { best = d; arg = kb + u; }
-                            inrange |= d < e2;
-                        }
-                    }
-                    if (g.deformable) live = live && inrange;
-                }
-#pragma unroll 1
-                for (int kb = 0; kb < K; kb += KU) {
-                    if (total + 64 * KU > POOL) { flush(total); total = 0; }
-#pragma unroll
-                    for (int u = 0; u < KU; ++u) {
-                        const int k = kb + u;
-                        const float d = kp_d2(nx, ny, nz, kp, k);
-                        float w = kp_weight(d, g, inv_extent);
-                        if (g.aggregation == WS_AGGREGATION_CLOSEST && k != arg) w = 0.0f;
-                        if (!live) w = 0.0f;
-                        if (modulations && w != 0.0f) w *= modulations[(int64_t)q * K + k];
-                        const bool nzw = w != 0.0f;
-                        const unsigned long long m = __ballot(nzw);
-                        if (nzw) pool[total + lane_rank(m)] = make_uint2((unsigned)(q * K + k), __float_as_uint(w));
-                        total += __builtin_popcountll(m);
+                const float* lkp = deformed_kp ? deformed_kp + (int64_t)q * (3 * K) : kernel_points;   // per lane if deformed
+                const float* lmod = modulations ? modulations + (int64_t)q * K : nullptr;
+                auto kp = [&](int k, int c) { return MODE == 0 ? kpr[MODE == 0 ? 3 * k + c : 0] : lkp[3 * k + c]; };
+                auto nomin = [&](int, float) {};
+                int total = 0, maxlen = 0;
+                kp_list<K, MODE>(nx, ny, nz, real, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod, pool, segs, lane, total,
+                                 maxlen, nomin);
+                if (total <= POOL) {
+                    flush(total);
+                } else {
+                    for (int sub = 0; sub < 4; ++sub) {
+                        total = 0; maxlen = 0;
+                        kp_list<K, MODE>(nx, ny, nz, real && (lane >> 4) == sub, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod,
+                                         pool, segs, lane, total, maxlen, nomin);
+                        flush(total);
                     }
                 }
             }
-            flush(total);
             // sum the S slots
 #pragma unroll
             for (int o = G; o < 64; o <<= 1) {
@@ -593,17 +638,19 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
     GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(nq, 4);
-    WS_REQUIRE(ns < (1ll << 27), "ns exceeds the 2^27 rows the entry pool can tag");
+    WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
     const int vec4 = (ci % 4 == 0) && aligned16(x) && aligned16(wf);
-#define WS_FWD2(G, DEFV, VECV)                                                                                     \
-    kpconv_gather_fwd_kernel<15, G, DEFV, VECV><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,           \
-                                                                      kernel_points, deformed_kp, modulations, g, wf, \
-                                                                      min_d2, order)
-#define WS_FWD(G)                                                         \
-    do {                                                                  \
-        if (deformed_kp) { if (vec4) WS_FWD2(G, true, true); else WS_FWD2(G, true, false); }    \
-        else { if (vec4) WS_FWD2(G, false, true); else WS_FWD2(G, false, false); }              \
+#define WS_FWD2(G, MODEV, DEFV, VECV)                                                                              \
+    kpconv_gather_fwd_kernel<15, G, MODEV, DEFV, VECV><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,   \
+                                                                             kernel_points, deformed_kp, modulations, \
+                                                                             g, wf, min_d2, order)
+#define WS_FWD(G)                                                                                   \
+    do {                                                                                            \
+        if (deformed_kp) { if (vec4) WS_FWD2(G, 1, true, true); else WS_FWD2(G, 1, true, false); }  \
+        else if (fast) { if (vec4) WS_FWD2(G, 0, false, true); else WS_FWD2(G, 0, false, false); }  \
+        else { if (vec4) WS_FWD2(G, 1, false, true); else WS_FWD2(G, 1, false, false); }            \
     } while (0)
+    const bool fast = influence == WS_INFLUENCE_LINEAR && aggregation == WS_AGGREGATION_SUM;
     if (ci <= 4) WS_FWD(1);
     else if (ci <= 8) WS_FWD(2);
     else if (ci <= 16) WS_FWD(4);
@@ -627,17 +674,21 @@ int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, i
     if (ns == 0) return WS_OK;
     WS_REQUIRE(t_offsets && t_pairs && dwf && dx && (kernel_points || deformed_kp), "NULL argument");
     WS_REQUIRE(nq * (int64_t)h < (1ll << 31), "nq*h exceeds int32");
+    WS_REQUIRE(nq * (int64_t)k * ci < (1ll << 31), "nq*k*ci exceeds the 32-bit row offsets of the gather");
     GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && aligned16(dwf) && aligned16(dx);
-#define WS_BWD2(G, VECV)                                                                                              \
-    kpconv_gather_bwd_x_kernel<15, G, VECV><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, dwf, ci, \
-                                                                  kernel_points, deformed_kp, modulations, g, dx, order)
-#define WS_BWD(G)                                        \
-    do {                                                 \
-        if (vec4) WS_BWD2(G, true); else WS_BWD2(G, false); \
+#define WS_BWD2(G, MODEV, VECV)                                                                                       \
+    kpconv_gather_bwd_x_kernel<15, G, MODEV, VECV><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs,  \
+                                                                         dwf, ci, kernel_points, deformed_kp,          \
+                                                                         modulations, g, dx, order)
+#define WS_BWD(G)                                                                       \
+    do {                                                                                \
+        if (fast) { if (vec4) WS_BWD2(G, 0, true); else WS_BWD2(G, 0, false); }          \
+        else { if (vec4) WS_BWD2(G, 1, true); else WS_BWD2(G, 1, false); }               \
     } while (0)
+    const bool fast = !deformed_kp && !modulations && influence == WS_INFLUENCE_LINEAR && aggregation == WS_AGGREGATION_SUM;
     if (ci <= 4) WS_BWD(1);
     else if (ci <= 8) WS_BWD(2);
     else if (ci <= 16) WS_BWD(4);
