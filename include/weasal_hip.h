@@ -181,6 +181,16 @@ int ws_radius_neighbors_search(ws_neighbors_ws* ws,
                                const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
                                float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
                                int32_t* h_max_count, void* stream);
+/* Same single pass without any host synchronisation: the true max count is written to the DEVICE
+ * int32 *d_max_count.  The rows are exact when that value is <= 128 (the sort slab of the fast
+ * kernel); the caller checks the value later (e.g. once per batch for all its searches) and repeats
+ * a search with ws_radius_neighbors_search if it was larger, or trims columns if it was smaller than
+ * `width`.  An empty result shows as *d_max_count == 0. */
+int ws_radius_neighbors_search_async(ws_neighbors_ws* ws,
+                                     const float* queries, int64_t nq, const float* supports, int64_t ns,
+                                     const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                                     float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
+                                     int32_t* d_max_count, void* stream);
 /* supports of the last plan/search in cell order (device int32 [ns], a permutation): a spatially
  * coherent scheduling order for the kernels that take `order`. */
 int ws_radius_neighbors_order(const ws_neighbors_ws* ws, int32_t* out_order, void* stream);

@@ -43,6 +43,8 @@ SIGNATURES = {
     "ws_radius_neighbors_fill": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "ws_radius_neighbors_search": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp,
                                             C.POINTER(_i32), _vp]),
+    "ws_radius_neighbors_search_async": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _vp, _vp,
+                                                  _vp, _vp]),
     "ws_radius_neighbors_order": (C.c_int, [_vp, _vp, _vp]),
     "ws_radius_neighbors_counts": (_vp, [_vp]),
     "ws_subsample_ws_create": (C.c_int, [C.POINTER(_vp)]),

@@ -122,39 +122,48 @@ __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// partial[c][K,N] = X[rows of chunk c, K]^T * Y[rows of chunk c, N].  Workgroup = 128 k-rows x
-// (32*NT) columns of the output for one chunk of `chunk` tall rows; wave w owns k-rows 32w..32w+31.
+// partial[c][K,N] = X[rows of chunk c, K]^T * Y[rows of chunk c, N].  Workgroup = (32*KT) k-rows x
+// (32*NT) columns of the output for one chunk of tall rows.  The 4 waves are KT k-tiles x RG = 4/KT
+// row groups: for narrow X (K <= 32 / 64) the waves split the tall rows of every LDS tile instead of
+// idling on zero padding, and their accumulators are summed through LDS at the end (fixed order).
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int KT>
 __global__ __launch_bounds__(256) void gemm_xty_kernel(const float* __restrict__ x, int64_t m, int k, int64_t ldx,
                                                         const float* __restrict__ yy, int n, int64_t ldy,
                                                         float* __restrict__ partial, int64_t chunk, int vecx, int vecy)
 {
     constexpr int BN = 32 * NT;
-    constexpr int BKO = 128;   // output rows (= columns of X) per workgroup
-    __shared__ __attribute__((aligned(16))) float Xs[BK][BKO];
-    __shared__ __attribute__((aligned(16))) float Ys[BK][BN];
+    constexpr int BKO = 32 * KT;   // output rows (= columns of X) per workgroup
+    constexpr int RG = 4 / KT;     // row groups
+    constexpr int XS_FLOATS = BK * BKO, YS_FLOATS = BK * BN;
+    constexpr int RED_FLOATS = (RG > 1) ? KT * NT * 16 * 64 : 0;
+    constexpr int LDS_FLOATS = (XS_FLOATS + YS_FLOATS) > RED_FLOATS ? (XS_FLOATS + YS_FLOATS) : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    float (*Xs)[BKO] = reinterpret_cast<float (*)[BKO]>(lds);
+    float (*Ys)[BN] = reinterpret_cast<float (*)[BN]>(lds + XS_FLOATS);
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63;
+    const int kt = wave % KT, rg = wave / KT;
     const int k0 = blockIdx.y * BKO;
     const int n0 = blockIdx.z * BN;
     const int64_t mbeg = (int64_t)blockIdx.x * chunk;
     const int64_t mend = mbeg + chunk < m ? mbeg + chunk : m;
-    constexpr int YPT = (BK * BN / 4 + 255) / 256;
+    constexpr int XPT = (XS_FLOATS / 4 + 255) / 256;
+    constexpr int YPT = (YS_FLOATS / 4 + 255) / 256;
     f32x16 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    float4 xv[4], yv[YPT];
+    float4 xv[XPT], yv[YPT];
     auto load_tiles = [&](int64_t r0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {             // X tile [32 rows][128 cols]: 1024 float4
+        for (int i = 0; i < XPT; ++i) {
             const int idx = t + 256 * i;
-            const int rr = idx >> 5, cc = (idx & 31) * 4;
-            xv[i] = ld4_guard(x, r0 + rr, mend, k0 + cc, k, ldx, vecx);
+            const int rr = idx / (BKO / 4), cc = (idx % (BKO / 4)) * 4;
+            xv[i] = (rr < BK) ? ld4_guard(x, r0 + rr, mend, k0 + cc, k, ldx, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < YPT; ++i) {
@@ -165,9 +174,10 @@ __global__ __launch_bounds__(256) void gemm_xty_kernel(const float* __restrict__
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XPT; ++i) {
             const int idx = t + 256 * i;
-            *reinterpret_cast<float4*>(&Xs[idx >> 5][(idx & 31) * 4]) = xv[i];
+            const int rr = idx / (BKO / 4), cc = (idx % (BKO / 4)) * 4;
+            if (rr < BK) *reinterpret_cast<float4*>(&Xs[rr][cc]) = xv[i];
         }
 #pragma unroll
         for (int i = 0; i < YPT; ++i) {
@@ -178,13 +188,14 @@ __global__ __launch_bounds__(256) void gemm_xty_kernel(const float* __restrict__
     };
 
     load_tiles(mbeg);
-    const int ai = wave * 32 + (lane & 31), kk = lane >> 5, bj = lane & 31;
+    const int ai = kt * 32 + (lane & 31), kk = lane >> 5, bj = lane & 31;
     for (int64_t r0 = mbeg; r0 < mend; r0 += BK) {
         store_tiles();
         __syncthreads();
         if (r0 + BK < mend) load_tiles(r0 + BK);
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
+        for (int ss = 0; ss < BK / 2 / RG; ++ss) {
+            const int s = ss * RG + rg;
             const float a = Xs[2 * s + kk][ai];          // A[i = output row][k = tall index]
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
@@ -194,14 +205,36 @@ __global__ __launch_bounds__(256) void gemm_xty_kernel(const float* __restrict__
         }
         __syncthreads();
     }
-    float* out = partial + (int64_t)blockIdx.x * k * n;
+    if (RG > 1) {
+        // sum the row groups in order rg = 1, 2, 3 onto rg = 0 (layout [kt][i][r][lane])
+        float* red = lds;
+        for (int src = 1; src < RG; ++src) {
+            if (rg == src) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int col = n0 + 32 * i + (lane & 31);
+                for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = k0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < k && col < n) out[(int64_t)row * n + col] = acc[i][r];
+                    for (int r = 0; r < 16; ++r) red[((kt * NT + i) * 16 + r) * 64 + lane] = acc[i][r];
+            }
+            __syncthreads();
+            if (rg == 0) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] += red[((kt * NT + i) * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (rg == 0) {
+        float* out = partial + (int64_t)blockIdx.x * k * n;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int col = n0 + 32 * i + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < k && col < n) out[(int64_t)row * n + col] = acc[i][r];
+            }
         }
     }
 }
@@ -289,15 +322,20 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
     const int vecx = al16(x) && (ldx % 4 == 0);
     const int vecy = al16(y) && (ldy % 4 == 0);
     float* partial = chunks == 1 ? out : (float*)scratch;
-    const unsigned gy = (unsigned)ws_ceil_div(k, 128);
-    if (n <= 32) {
-        gemm_xty_kernel<1><<<dim3(chunks, gy, 1), 256, 0, st>>>(x, m, k, ldx, y, n, ldy, partial, chunk, vecx, vecy);
-    } else if (n <= 64) {
-        gemm_xty_kernel<2><<<dim3(chunks, gy, 1), 256, 0, st>>>(x, m, k, ldx, y, n, ldy, partial, chunk, vecx, vecy);
-    } else {
-        gemm_xty_kernel<4><<<dim3(chunks, gy, (unsigned)ws_ceil_div(n, 128)), 256, 0, st>>>(x, m, k, ldx, y, n, ldy, partial,
-                                                                                           chunk, vecx, vecy);
-    }
+#define WS_XTY(NTV, KTV)                                                                                              \
+    gemm_xty_kernel<NTV, KTV><<<dim3(chunks, (unsigned)ws_ceil_div(k, 32 * KTV), (unsigned)ws_ceil_div(n, 32 * NTV)), 256, 0, \
+                                st>>>(x, m, k, ldx, y, n, ldy, partial, chunk, vecx, vecy)
+#define WS_XTY_K(NTV)                    \
+    do {                                 \
+        if (k <= 32) WS_XTY(NTV, 1);     \
+        else if (k <= 64) WS_XTY(NTV, 2); \
+        else WS_XTY(NTV, 4);             \
+    } while (0)
+    if (n <= 32) WS_XTY_K(1);
+    else if (n <= 64) WS_XTY_K(2);
+    else WS_XTY_K(4);
+#undef WS_XTY_K
+#undef WS_XTY
     WS_LAUNCH_CHECK();
     if (chunks > 1) {
         const int64_t elems = (int64_t)k * n;

@@ -58,6 +58,16 @@ __global__ __launch_bounds__(1024) void nb_bbox_kernel(const float* __restrict__
     }
 }
 
+// The per-element table travels as a kernel argument (copied at launch): no host staging buffer
+// whose lifetime would force a stream synchronisation.
+constexpr int GRID_TABLE_MAX = 48;
+struct GridTable { CloudGrid g[GRID_TABLE_MAX]; };
+__global__ void nb_upload_kernel(GridTable t, int nb, CloudGrid* __restrict__ dst)
+{
+    const int b = threadIdx.x;
+    if (b < nb) dst[b] = t.g[b];
+}
+
 __global__ void nb_grid_setup_kernel(CloudGrid* __restrict__ grids, const float* __restrict__ bbox, int nb, float radius)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -479,8 +489,15 @@ static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, con
     if ((rc = ws->sorted.ensure((size_t)ns))) return rc;
     if ((rc = ws->order.ensure((size_t)ns))) return rc;
 
-    WS_HIP(hipMemcpyAsync(ws->grids.p, hg.data(), sizeof(CloudGrid) * (size_t)nb, hipMemcpyHostToDevice, st));
-    WS_HIP(hipStreamSynchronize(st));   // hg is a stack-lifetime staging buffer
+    if (nb <= GRID_TABLE_MAX) {
+        GridTable tbl;
+        for (int b = 0; b < nb; ++b) tbl.g[b] = hg[(size_t)b];
+        nb_upload_kernel<<<1, 64, 0, st>>>(tbl, nb, ws->grids.p);
+        WS_LAUNCH_CHECK();
+    } else {
+        WS_HIP(hipMemcpyAsync(ws->grids.p, hg.data(), sizeof(CloudGrid) * (size_t)nb, hipMemcpyHostToDevice, st));
+        WS_HIP(hipStreamSynchronize(st));   // hg is a stack-lifetime staging buffer
+    }
     nb_bbox_kernel<<<nb, 1024, 0, st>>>(supports, ws->grids.p, ws->bbox.p);
     WS_LAUNCH_CHECK();
     nb_grid_setup_kernel<<<(nb + 63) / 64, 64, 0, st>>>(ws->grids.p, ws->bbox.p, nb, radius);
@@ -579,6 +596,24 @@ int ws_radius_neighbors_search(ws_neighbors_ws* ws, const float* queries, int64_
         if (mc <= cap) return WS_OK;
         cap = mc;      // a row overflowed the sort slab: run once more with a slab that fits
     }
+}
+
+int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
+                                     int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                                     float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
+                                     int32_t* d_max_count, void* stream)
+{
+    WS_REQUIRE(d_max_count, "NULL argument");
+    WS_REQUIRE((out_i32 != nullptr) != (out_i64 != nullptr), "exactly one of out_i32 / out_i64 must be given");
+    WS_REQUIRE(width >= 1, "width must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
+    if (rc) { if (ws) ws->nq = 0; return rc; }
+    WS_HIP(hipMemsetAsync(ws->max_count.p, 0, sizeof(int32_t), st));
+    if ((rc = nb_launch_fill(ws, 128, width, out_i32, out_i64, true, st))) return rc;
+    WS_HIP(hipMemcpyAsync(d_max_count, ws->max_count.p, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    ws->max_count_host = 128;   // unknown on the host; rows beyond 128 are reported through d_max_count
+    return WS_OK;
 }
 
 int ws_radius_neighbors_fill(ws_neighbors_ws* ws, int32_t width, int32_t* out_i32, int64_t* out_i64, void* stream)

@@ -410,6 +410,59 @@ def radius_neighbors(queries, supports, q_lens, s_lens, radius, limit=None, dtyp
     return res[0] if len(res) == 1 else tuple(res)
 
 
+class DeferredSearches:
+    """Batch of radius searches issued without host synchronisation (ws_radius_neighbors_search_async).
+    ``add`` returns the index matrix immediately ([Nq, limit], rows padded with Ns); ``finish`` reads
+    all true widths back in ONE synchronisation and returns the final matrices: trimmed to the true
+    width where that is smaller than the limit (what the reference's crop yields), recomputed with the
+    synchronous search in the rare case of a row with more than 128 neighbours."""
+
+    def __init__(self, device, capacity=64):
+        self.device = device
+        self.slots = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self.calls = []
+
+    def add(self, queries, supports, q_lens, s_lens, radius, limit, want_order=False):
+        import ctypes as C
+        lib = _lib.lib()
+        q, s = _f32c(queries), _f32c(supports)
+        ql, sl = _host_lens(q_lens), _host_lens(s_lens)
+        if ql.shape[0] != sl.shape[0]:
+            raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
+        if len(self.calls) >= self.slots.shape[0]:
+            raise RuntimeError("DeferredSearches capacity exceeded")
+        ws = _ws.neighbors(q.device)
+        width = max(1, int(limit))
+        out = torch.empty((q.shape[0], width), dtype=torch.int64, device=q.device)
+        slot = len(self.calls)
+        with torch.cuda.device(q.device):
+            check(lib.ws_radius_neighbors_search_async(
+                ws, ptr(q), q.shape[0], ptr(s), s.shape[0], C.c_void_p(ql.ctypes.data), C.c_void_p(sl.ctypes.data),
+                ql.shape[0], float(np.float32(radius)), width, None, ptr(out),
+                C.c_void_p(self.slots.data_ptr() + 4 * slot), current_stream()))
+            order = None
+            if want_order:
+                order = torch.empty(s.shape[0], dtype=torch.int32, device=q.device)
+                check(lib.ws_radius_neighbors_order(ws, ptr(order), current_stream()))
+        self.calls.append((out, (q, s, ql, sl, radius, width)))
+        return (out, order) if want_order else out
+
+    def finish(self):
+        counts = self.slots[:len(self.calls)].cpu().numpy() if self.calls else []
+        final = []
+        for (out, args), mc in zip(self.calls, counts):
+            q, s, ql, sl, radius, width = args
+            if mc == 0:
+                raise _lib.WeasalHipError("libweasal_hip status 4: Error")
+            if mc > 128:
+                out = radius_neighbors(q, s, ql, sl, radius, limit=width, dtype=torch.int64)
+            elif mc < width:
+                out = out[:, :int(mc)].contiguous()
+            final.append(out)
+        self.calls = []
+        return final
+
+
 def grid_subsample(points, lens, dl, max_p=0, features=None, labels=None, reference_order=True,
                    return_keys=False):
     """Batched grid subsampling on device tensors (reference: cpp_subsampling.subsample_batch,

@@ -54,16 +54,28 @@ def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_gr
 def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_lengths,
                         neighborhood_limits=(), random_grid_orient=True):
     """-> flat list  points[L] + neighbors[L] + pools[L] + upsamples[L] + lengths[L] + [features, labels]
-    (datasets/common.py:574-575), all device tensors (lengths int32, indices int64)."""
+    (datasets/common.py:574-575), all device tensors (lengths int32, indices int64).
+
+    With neighbourhood limits (the normal case after calibration) the searches run without host
+    synchronisation and their true widths are checked once at the end (ops.DeferredSearches); without
+    limits every search needs its width on the host first (two-call protocol)."""
     dev = stacked_points.device
     stacked_points = stacked_points.detach().to(torch.float32).contiguous()
     ops.clear_point_orders()
     lens = np.asarray(stack_lengths.cpu() if isinstance(stack_lengths, torch.Tensor) else stack_lengths, dtype=np.int32)
     r_normal = config.first_subsampling_dl * config.conv_radius
     limits = list(neighborhood_limits)
+    deferred = ops.DeferredSearches(dev) if len(limits) > 0 else None
+    slots = []   # (list, position) of every deferred matrix
 
-    def limit(layer):
-        return limits[layer] if len(limits) > 0 else None
+    def search(q, s, ql, sl, r, layer, register_order=False):
+        if deferred is None:
+            return batch_neighbors(q, s, ql, sl, r, None, register_order=register_order)
+        if register_order:
+            inds, order = deferred.add(q, s, ql, sl, r, limits[layer], want_order=True)
+            ops.register_point_order(s, order)
+            return inds
+        return deferred.add(q, s, ql, sl, r, limits[layer])
 
     layer_blocks = []
     input_points, input_neighbors, input_pools, input_upsamples, input_lengths = [], [], [], [], []
@@ -78,7 +90,9 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
                 r = r_normal * config.deform_radius / config.conv_radius
             else:
                 r = r_normal
-            conv_i = batch_neighbors(stacked_points, stacked_points, lens, lens, r, limit(layer), register_order=True)
+            conv_i = search(stacked_points, stacked_points, lens, lens, r, layer, register_order=True)
+            if deferred is not None:
+                slots.append((input_neighbors, layer))
         else:
             conv_i = empty_i()
         if 'pool' in block or 'strided' in block:
@@ -86,8 +100,12 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
             pool_p, pool_b = batch_grid_subsampling(stacked_points, lens, sampleDl=dl,
                                                     random_grid_orient=random_grid_orient)
             r = r_normal * config.deform_radius / config.conv_radius if 'deformable' in block else r_normal
-            pool_i = batch_neighbors(pool_p, stacked_points, pool_b, lens, r, limit(layer))
-            up_i = batch_neighbors(stacked_points, pool_p, lens, pool_b, 2 * r, limit(layer + 1))
+            pool_i = search(pool_p, stacked_points, pool_b, lens, r, layer)
+            if deferred is not None:
+                slots.append((input_pools, layer))
+            up_i = search(stacked_points, pool_p, lens, pool_b, 2 * r, layer + 1)
+            if deferred is not None:
+                slots.append((input_upsamples, layer))
         else:
             pool_i = empty_i()
             pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
@@ -103,6 +121,9 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
         layer_blocks = []
         if 'global' in block or 'upsample' in block:
             break
+    if deferred is not None:
+        for (lst, pos), mat in zip(slots, deferred.finish()):
+            lst[pos] = mat
     return (input_points + input_neighbors + input_pools + input_upsamples + input_lengths
             + [stacked_features, labels])
 
