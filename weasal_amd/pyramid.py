@@ -62,6 +62,7 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
     dev = stacked_points.device
     stacked_points = stacked_points.detach().to(torch.float32).contiguous()
     ops.clear_point_orders()
+    ops.clear_table_cache()      # transposed tables belong to one batch: keep the footprint per step constant
     lens = np.asarray(stack_lengths.cpu() if isinstance(stack_lengths, torch.Tensor) else stack_lengths, dtype=np.int32)
     r_normal = config.first_subsampling_dl * config.conv_radius
     limits = list(neighborhood_limits)
