@@ -142,6 +142,12 @@ int ws_closest_pool_bwd(const float* dy, int64_t nq, int32_t h, int32_t c,
  * ------------------------------------------------------------------------------------------ */
 int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                float* y, int64_t ldy, void* stream);
+/* y = act(x @ b + bias[n] + residual[m,n]) -- the BatchNormBlock bias (models/blocks.py:465), the
+ * residual sum and LeakyReLU(0.1) of the blocks (blocks.py:497-500, :563-564, :709) applied in the GEMM
+ * epilogue.  bias / residual may be NULL; act: 0 = none, 1 = LeakyReLU(slope). */
+int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+                        const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
+                        float* y, int64_t ldy, void* stream);
 int64_t ws_gemm_xty_scratch_bytes(int64_t m, int32_t k, int32_t n);
 int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
                 float* out, void* scratch, void* stream);
@@ -234,6 +240,11 @@ int ws_grid_subsample_fill(ws_subsample_ws* ws,
  * the arithmetic of datasets/common.py:116-119 and :131-135 (random grid orientation). */
 int ws_rotate_clouds(const float* points, int64_t n, const int32_t* lens /*device [nb]*/, int32_t nb,
                      const float* rot /*device [nb,3,3]*/, int32_t transpose, float* out, void* stream);
+
+/* same with HOST lengths / matrices (h_lens [nb], h_rot [nb,3,3]), passed as a kernel argument: no
+ * host-to-device copy and no synchronisation; nb <= 64 (WS_ERR_UNSUPPORTED beyond). */
+int ws_rotate_clouds_host(const float* points, int64_t n, const int32_t* h_lens, int32_t nb,
+                          const float* h_rot, int32_t transpose, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,13 +81,36 @@ def closest_pool_ref(x, inds):
     return x_pad[inds.long()[:, 0]]
 
 
+def matmul_ref(x, b):
+    return torch.matmul(x, b)
+
+
+def linear_ref(x, weight):
+    """nn.Linear without bias (blocks.py:490,497)"""
+    return torch.matmul(x, weight.t())
+
+
+def matmul_epilogue_ref(x, b, bias=None, residual=None, slope=None):
+    """x @ b, then the bias of BatchNormBlock (blocks.py:465), the residual sum and LeakyReLU (blocks.py:497-500,709)"""
+    y = torch.matmul(x, b)
+    if bias is not None:
+        y = y + bias
+    if residual is not None:
+        y = y + residual
+    return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
+
+
 @contextlib.contextmanager
 def cpu_reference_mode():
     """Evaluate weasal_amd.blocks / architectures modules with the restatements above (CPU)."""
     from weasal_amd import ops
-    saved = (ops.kpconv_gather, ops.max_pool, ops.closest_pool)
-    ops.kpconv_gather, ops.max_pool, ops.closest_pool = kpconv_gather_ref, max_pool_ref, closest_pool_ref
+    names = ("kpconv_gather", "max_pool", "closest_pool", "matmul", "linear", "matmul_epilogue")
+    saved = [getattr(ops, n) for n in names]
+    for n, f in zip(names, (kpconv_gather_ref, max_pool_ref, closest_pool_ref, matmul_ref, linear_ref,
+                            matmul_epilogue_ref)):
+        setattr(ops, n, f)
     try:
         yield
     finally:
-        ops.kpconv_gather, ops.max_pool, ops.closest_pool = saved
+        for n, f in zip(names, saved):
+            setattr(ops, n, f)

@@ -132,6 +132,9 @@ def test_rotate_clouds(gpu):
     want_t[300:] = np.sum(np.expand_dims(p[300:], 2) * R[1].T, axis=1)
     got = ops.rotate_clouds(dev(p, gpu), dev(lens, gpu), dev(R, gpu), transpose=True).cpu().numpy()
     assert np.array_equal(got, want_t)
+    # host-table form (no H2D copy of lengths / matrices)
+    assert np.array_equal(ops.rotate_clouds_host(dev(p, gpu), lens, R).cpu().numpy(), want)
+    assert np.array_equal(ops.rotate_clouds_host(dev(p, gpu), lens, R, transpose=True).cpu().numpy(), want_t)
 
 
 def test_full_size_dales_batch(gpu):

@@ -172,3 +172,41 @@ def test_skinny_gemm_vs_float64(gpu, m, k, n):
     w = torch.randn(n, k, device=gpu) / k ** 0.5
     xs = torch.randn(m, k + 8, device=gpu)[:, 4:4 + k]
     assert rel(ops.linear(xs, w), xs.double() @ w.double().t()) < 2e-6
+
+
+@pytest.mark.parametrize("m,k,n,with_bias,with_res,slope", [(5000, 64, 32, True, False, 0.1), (20000, 32, 128, False, True, 0.1),
+                                                             (9000, 128, 9, True, False, 0.1), (6000, 480, 64, True, True, None)])
+def test_gemm_epilogue_vs_torch(gpu, m, k, n, with_bias, with_res, slope):
+    """bias + residual + LeakyReLU in the GEMM epilogue == the separate torch ops (blocks.py:497-500,709)"""
+    from weasal_amd import ops
+    torch.manual_seed(n)
+    mk = lambda *s: torch.randn(*s, device=gpu, dtype=torch.float64)
+    x, b = mk(m, k), mk(k, n) / k ** 0.5
+    bias = mk(n) if with_bias else None
+    res = mk(m, n) if with_res else None
+    dy = mk(m, n)
+    leaves64 = [t.clone().requires_grad_(True) for t in (x, b) + ((bias,) if with_bias else ()) + ((res,) if with_res else ())]
+    leaves32 = [t.detach().float().clone().requires_grad_(True) for t in leaves64]
+
+    def run(leaves, fused):
+        it = iter(leaves)
+        xx, bb = next(it), next(it)
+        bi = next(it) if with_bias else None
+        rr = next(it) if with_res else None
+        if fused:
+            return ops.matmul_epilogue(xx, bb, bias=bi, residual=rr, slope=slope)
+        y = xx @ bb
+        if bi is not None:
+            y = y + bi
+        if rr is not None:
+            y = y + rr
+        return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
+
+    y64 = run(leaves64, False)
+    y64.backward(dy)
+    y32 = run(leaves32, True)
+    y32.backward(dy.float())
+    rel = lambda a, r: ((a.double() - r).abs().max() / r.abs().max()).item()
+    assert rel(y32.detach(), y64.detach()) < 5e-6
+    for a, r in zip(leaves32, leaves64):
+        assert rel(a.grad, r.grad) < 5e-5

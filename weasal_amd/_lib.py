@@ -34,6 +34,7 @@ SIGNATURES = {
     "ws_closest_pool_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
     "ws_closest_pool_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "ws_gemm_xb": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i64, _vp]),
+    "ws_gemm_xb_epilogue": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
     "ws_gemm_xty_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "ws_gemm_xty": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp]),
     "ws_neighbors_ws_create": (C.c_int, [C.POINTER(_vp)]),
@@ -53,6 +54,7 @@ SIGNATURES = {
                                         C.POINTER(_i64), _vp]),
     "ws_grid_subsample_fill": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws_rotate_clouds": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "ws_rotate_clouds_host": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
 }
 
 _lib = None

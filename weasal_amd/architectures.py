@@ -115,9 +115,8 @@ class KPFCNN(nn.Module):
         c_up = x.shape[1]
         w = unary.mlp.weight
         y = closest_pool(ops.linear(x, w[:, :c_up]), batch.upsamples[up_block.layer_ind - 1])
-        y = y + ops.linear(skip, w[:, c_up:])
-        y = unary.batch_norm(y)
-        return y if unary.no_relu else unary.leaky_relu(y)
+        return ops.matmul_epilogue(skip, w[:, c_up:].t(), bias=unary.batch_norm.epilogue_bias(), residual=y,
+                                   slope=None if unary.no_relu else 0.1)
 
     def forward(self, batch, config):
         x = batch.features.clone().detach()

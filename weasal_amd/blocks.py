@@ -7,7 +7,8 @@ What differs is the implementation: ``KPConv.forward`` never materialises the
 [N,H,3] / [N,H,K,3] / [N,H,K] / [N,H,Ci] tensors of blocks.py:278-363 -- the gather, the
 kernel-point influence and the feature aggregate run fused in one HIP kernel
 (weasal_amd/csrc/kpconv.hip); the remaining dense contraction [N, K*Ci] x [K*Ci, Co] and the unary
-MLPs are plain GEMMs (rocBLAS/hipBLASLt through torch, i.e. MFMA).
+MLPs run on the f32 MFMA (weasal_amd/csrc/gemm.hip) with the bias / residual / LeakyReLU that follow
+them in the blocks applied in the GEMM epilogue.
 
 Quirks of the reference that are preserved on purpose:
   * BatchNormBlock is an identity for 2-D inputs when use_bn is set (blocks.py:454-463); the
@@ -110,7 +111,9 @@ class KPConv(nn.Module):
         k_points = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
         return Parameter(torch.tensor(k_points, dtype=torch.float32), requires_grad=False)
 
-    def forward(self, q_pts, s_pts, neighb_inds, x):
+    def forward(self, q_pts, s_pts, neighb_inds, x, _bias=None, _slope=None):
+        """`_bias` / `_slope` (used by the blocks of this module only): the BatchNormBlock bias and the
+        LeakyReLU that follow the convolution, applied in the epilogue of the contraction GEMM."""
         if self.KP_influence not in ops.INFLUENCE:
             raise ValueError('Unknown influence function type (config.KP_influence)')
         if self.aggregation_mode not in ops.AGGREGATION:
@@ -137,8 +140,9 @@ class KPConv(nn.Module):
         if self.deformable:
             self.min_d2 = min_d2                                                     # blocks.py:304
         # dense contraction over (kernel point, input channel): blocks.py:370-374
-        return ops.matmul(wf.reshape(wf.shape[0], -1),
-                          self.weights.reshape(self.K * self.in_channels, self.out_channels))
+        return ops.matmul_epilogue(wf.reshape(wf.shape[0], -1),
+                                   self.weights.reshape(self.K * self.in_channels, self.out_channels),
+                                   bias=_bias, slope=_slope)
 
     def __repr__(self):
         return 'KPConv(radius: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(self.radius, self.in_channels,
@@ -187,6 +191,10 @@ class BatchNormBlock(nn.Module):
     def reset_parameters(self):
         nn.init.zeros_(self.bias)
 
+    def epilogue_bias(self):
+        """what this block adds to a 2-D input: nothing with use_bn (identity), the bias otherwise"""
+        return None if self.use_bn else self.bias
+
     def forward(self, x):
         if not self.use_bn:
             return x + self.bias
@@ -217,8 +225,15 @@ class UnaryBlock(nn.Module):
             self.leaky_relu = nn.LeakyReLU(0.1)
 
     def forward(self, x, batch=None):
-        x = self.batch_norm(ops.linear(x, self.mlp.weight))
-        return x if self.no_relu else self.leaky_relu(x)
+        return self.forward_fused(x)
+
+    def forward_fused(self, x, residual=None, slope_override=None):
+        """mlp -> batch_norm(identity | + bias) [-> + residual] -> LeakyReLU, in one GEMM.
+        slope_override: activation applied although the block itself has no_relu (the residual sum of
+        ResnetBottleneckBlock, blocks.py:709)."""
+        slope = slope_override if slope_override is not None else (None if self.no_relu else 0.1)
+        return ops.matmul_epilogue(x, self.mlp.weight.t(), bias=self.batch_norm.epilogue_bias(), residual=residual,
+                                   slope=slope)
 
     def __repr__(self):
         return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
@@ -257,7 +272,7 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
-        return self.leaky_relu(self.batch_norm(self.KPConv(q_pts, s_pts, inds, x)))
+        return self.KPConv(q_pts, s_pts, inds, x, _bias=self.batch_norm.epilogue_bias(), _slope=0.1)
 
 
 class SimpleBlock2(nn.Module):
@@ -277,7 +292,7 @@ class SimpleBlock2(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
-        return self.leaky_relu(self.batch_norm(self.KPConv(q_pts, s_pts, inds, x)))
+        return self.KPConv(q_pts, s_pts, inds, x, _bias=self.batch_norm.epilogue_bias(), _slope=0.1)
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -306,10 +321,10 @@ class ResnetBottleneckBlock(nn.Module):
     def forward(self, features, batch):
         q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
         x = self.unary1(features)
-        x = self.leaky_relu(self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x)))
-        x = self.unary2(x)
+        x = self.KPConv(q_pts, s_pts, inds, x, _bias=self.batch_norm_conv.epilogue_bias(), _slope=0.1)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
-        return self.leaky_relu(x + self.unary_shortcut(shortcut))
+        # leaky_relu(unary2(x) + unary_shortcut(shortcut)) with the sum and the activation in unary2's GEMM
+        return self.unary2.forward_fused(x, residual=self.unary_shortcut(shortcut), slope_override=0.1)
 
 
 class GlobalAverageBlock(nn.Module):

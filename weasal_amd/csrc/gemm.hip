@@ -49,7 +49,9 @@ __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ p, int64_t
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ x, int64_t m, int k, int64_t ldx,
                                                        const float* __restrict__ b, int n, int64_t ldb,
-                                                       float* __restrict__ y, int64_t ldy, int vecx, int vecb)
+                                                       float* __restrict__ y, int64_t ldy, int vecx, int vecb,
+                                                       const float* __restrict__ bias, const float* __restrict__ residual,
+                                                       int64_t ldr, int act, float slope)
 {
     constexpr int BN = 32 * NT;
     __shared__ float Xs[BM][BK + 1];
@@ -109,14 +111,20 @@ __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
-    // epilogue: 32 lanes write 128 contiguous bytes of one row
+    // epilogue (+ bias[col], + residual[row,col], LeakyReLU): 32 lanes write 128 contiguous bytes of one row
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int col = n0 + 32 * i + (lane & 31);
+        const float bv = (bias && col < n) ? bias[col] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < m && col < n) y[row * ldy + col] = acc[i][r];
+            if (row < m && col < n) {
+                float v = acc[i][r] + bv;
+                if (residual) v += residual[row * ldr + col];
+                if (act) v = v > 0.0f ? v : v * slope;
+                y[row * ldy + col] = v;
+            }
         }
     }
 }
@@ -277,10 +285,13 @@ int64_t xty_chunk(int64_t m, int k, int n)
 
 extern "C" {
 
-int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n, float* y, int64_t ldy,
-               void* stream)
+int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+                        const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
+                        float* y, int64_t ldy, void* stream)
 {
     WS_REQUIRE(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
+    WS_REQUIRE(!residual || ldr >= n, "residual leading dimension too small");
+    WS_REQUIRE(act == 0 || act == 1, "unknown activation %d", act);
     if (m == 0) return WS_OK;
     WS_REQUIRE(x && b && y, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
@@ -289,15 +300,24 @@ int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b
     const int64_t gx = ws_ceil_div(m, BM);
     WS_REQUIRE(gx < (1ll << 31), "m too large");
     if (n <= 32) {
-        gemm_xb_kernel<1><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb);
+        gemm_xb_kernel<1><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
+                                                                 act, slope);
     } else if (n <= 64) {
-        gemm_xb_kernel<2><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb);
+        gemm_xb_kernel<2><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
+                                                                 act, slope);
     } else {
         gemm_xb_kernel<4><<<dim3((unsigned)gx, (unsigned)ws_ceil_div(n, 128)), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy,
-                                                                                            vecx, vecb);
+                                                                                            vecx, vecb, bias, residual, ldr,
+                                                                                            act, slope);
     }
     WS_LAUNCH_CHECK();
     return WS_OK;
+}
+
+int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n, float* y, int64_t ldy,
+               void* stream)
+{
+    return ws_gemm_xb_epilogue(x, m, k, ldx, b, n, nullptr, nullptr, 0, 0, 0.0f, y, ldy, stream);
 }
 
 int64_t ws_gemm_xty_scratch_bytes(int64_t m, int32_t k, int32_t n)

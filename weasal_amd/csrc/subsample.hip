@@ -447,6 +447,31 @@ __global__ __launch_bounds__(256) void rotate_kernel(const float* __restrict__ p
     }
 }
 
+// host-side lengths and matrices travel as a kernel argument (copied at launch, no H2D staging copy
+// and no synchronisation); up to ROT_MAX batch elements
+constexpr int ROT_MAX = 64;
+struct RotTable { int32_t end[ROT_MAX]; float r[ROT_MAX * 9]; };
+__global__ __launch_bounds__(256) void rotate_table_kernel(const float* __restrict__ pts, int64_t n, RotTable t, int nb,
+                                                            int transpose, float* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int b = 0;
+        while (b + 1 < nb && i >= t.end[b]) ++b;
+        const float* R = t.r + 9 * b;
+        const float p0 = pts[3 * i], p1 = pts[3 * i + 1], p2 = pts[3 * i + 2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float r0 = transpose ? R[3 * j + 0] : R[0 + j];
+            const float r1 = transpose ? R[3 * j + 1] : R[3 + j];
+            const float r2 = transpose ? R[3 * j + 2] : R[6 + j];
+            float v = p0 * r0;
+            v = v + p1 * r1;
+            v = v + p2 * r2;
+            out[3 * i + j] = v;
+        }
+    }
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -658,6 +683,26 @@ int ws_rotate_clouds(const float* points, int64_t n, const int32_t* lens, int32_
     if (n == 0) return WS_OK;
     WS_REQUIRE(points && lens && rot && out, "NULL argument");
     rotate_kernel<<<ws_grid(n, 256), 256, 0, (hipStream_t)stream>>>(points, n, lens, nb, rot, transpose, out);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+int ws_rotate_clouds_host(const float* points, int64_t n, const int32_t* h_lens, int32_t nb, const float* h_rot,
+                          int32_t transpose, float* out, void* stream)
+{
+    WS_REQUIRE(n >= 0 && nb >= 1, "bad sizes");
+    if (n == 0) return WS_OK;
+    WS_REQUIRE(points && h_lens && h_rot && out, "NULL argument");
+    if (nb > ROT_MAX) return ws_fail(WS_ERR_UNSUPPORTED, "more than %d batch elements: use ws_rotate_clouds", ROT_MAX);
+    RotTable t;
+    int64_t acc = 0;
+    for (int b = 0; b < nb; ++b) {
+        acc += h_lens[b];
+        t.end[b] = (int32_t)acc;
+        for (int e = 0; e < 9; ++e) t.r[9 * b + e] = h_rot[9 * b + e];
+    }
+    WS_REQUIRE(acc == n, "batch lengths sum to %lld, expected %lld", (long long)acc, (long long)n);
+    rotate_table_kernel<<<ws_grid(n, 256), 256, 0, (hipStream_t)stream>>>(points, n, t, nb, transpose, out);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }

@@ -6,6 +6,7 @@ torch's current stream.  CPU tensors are rejected -- there is no CPU path in the
 (the CPU restatement lives in oracle/ and is test infrastructure).
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -188,6 +189,7 @@ def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linea
 # ------------------------------------------------------------------------------------------------
 # tall-skinny GEMMs (unary MLPs and the kernel contraction) on the f32 MFMA
 # ------------------------------------------------------------------------------------------------
+FUSED_EPILOGUE = os.environ.get("WEASAL_FUSED_EPILOGUE", "1") != "0"   # A/B switch (diagnostics)
 GEMM_MIN_ROWS = 4096     # below this the operand is no longer "tall": plain torch.matmul (rocBLAS)
 
 
@@ -228,9 +230,79 @@ class _MatmulXB(torch.autograd.Function):
         return dx, db
 
 
+def _rowmajor(t):
+    return t if (t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
+
+
+class _MatmulEpilogue(torch.autograd.Function):
+    """y = act(x @ b + bias + residual), act = LeakyReLU(slope) or identity; the activation
+    backward uses the output (sign(y) == sign(pre-activation) for slope > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, b, bias, residual, slope):
+        lib = _lib.lib()
+        xc, bc = _rowmajor(x), b.contiguous()
+        rc = _rowmajor(residual) if residual is not None else None
+        biasc = bias.contiguous() if bias is not None else None
+        m, k = xc.shape
+        n = bc.shape[1]
+        y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        check(lib.ws_gemm_xb_epilogue(ptr(xc), m, k, xc.stride(0), ptr(bc), n, ptr(biasc), ptr(rc),
+                                      rc.stride(0) if rc is not None else 0, 0 if slope is None else 1,
+                                      0.0 if slope is None else float(slope), ptr(y), n, current_stream()))
+        ctx.slope = slope
+        ctx.has = (bias is not None, residual is not None)
+        ctx.save_for_backward(xc, bc, y if slope is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.lib()
+        x, b, y = ctx.saved_tensors
+        dz = dy if ctx.slope is None else torch.ops.aten.leaky_relu_backward(dy, y, ctx.slope, True)
+        dz = _rowmajor(dz)
+        dx = db = dbias = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm_xb(dz, b.t().contiguous())
+        if ctx.needs_input_grad[1]:
+            m, k = x.shape
+            n = dz.shape[1]
+            db = torch.empty((k, n), dtype=torch.float32, device=x.device)
+            scratch = torch.empty(max(lib.ws_gemm_xty_scratch_bytes(m, k, n), 16), dtype=torch.uint8, device=x.device)
+            check(lib.ws_gemm_xty(ptr(x), m, k, x.stride(0), ptr(dz), n, dz.stride(0), ptr(db), ptr(scratch),
+                                  current_stream()))
+        if ctx.has[0] and ctx.needs_input_grad[2]:
+            dbias = dz.sum(0)
+        if ctx.has[1] and ctx.needs_input_grad[3]:
+            dres = dz
+        return dx, db, dbias, dres, None
+
+
+def matmul_epilogue(x, b, bias=None, residual=None, slope=None):
+    """act(x @ b + bias + residual): one MFMA kernel for tall operands (b is [K,N]); short operands
+    (deep layers, < GEMM_MIN_ROWS rows) go to rocBLAS through torch -- still on the GPU."""
+    _need_cuda(x, b)
+    if FUSED_EPILOGUE and x.dim() == 2 and x.shape[0] >= GEMM_MIN_ROWS and x.dtype == torch.float32:
+        return _MatmulEpilogue.apply(x, b, bias, residual, slope)
+    if not FUSED_EPILOGUE:
+        y = matmul(x, b)
+        if bias is not None:
+            y = y + bias
+        if residual is not None:
+            y = y + residual
+        return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
+    y = torch.matmul(x, b)
+    if bias is not None:
+        y = y + bias
+    if residual is not None:
+        y = y + residual
+    return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
+
+
 def matmul(x, b):
-    """x [M,K] @ b [K,N]: the MFMA kernels for tall device operands, torch.matmul otherwise"""
-    if x.is_cuda and x.dim() == 2 and b.dim() == 2 and x.shape[0] >= GEMM_MIN_ROWS and x.dtype == torch.float32:
+    """x [M,K] @ b [K,N]: the MFMA kernels for tall operands, rocBLAS (torch.matmul on the GPU) for short ones"""
+    _need_cuda(x, b)
+    if x.dim() == 2 and b.dim() == 2 and x.shape[0] >= GEMM_MIN_ROWS and x.dtype == torch.float32:
         return _MatmulXB.apply(x, b)
     return torch.matmul(x, b)
 
@@ -503,6 +575,24 @@ def grid_subsample(points, lens, dl, max_p=0, features=None, labels=None, refere
     if return_keys:
         res += [keys, cnts]
     return tuple(res)
+
+
+def rotate_clouds_host(points, lens, rot, transpose=False):
+    """rotate_clouds with HOST lengths (int32 [B]) and matrices (float32 [B,3,3]): they travel as a kernel
+    argument, so the call neither copies nor synchronises (up to 64 batch elements)."""
+    import ctypes as C
+    lib = _lib.lib()
+    _need_cuda(points)
+    p = _f32c(points)
+    hl = np.ascontiguousarray(lens, dtype=np.int32)
+    hr = np.ascontiguousarray(rot, dtype=np.float32)
+    if hl.shape[0] > 64:
+        dev = p.device
+        return rotate_clouds(p, torch.from_numpy(hl).to(dev), torch.from_numpy(hr).to(dev), transpose)
+    out = torch.empty_like(p)
+    check(lib.ws_rotate_clouds_host(ptr(p), p.shape[0], C.c_void_p(hl.ctypes.data), hl.shape[0],
+                                    C.c_void_p(hr.ctypes.data), 1 if transpose else 0, ptr(out), current_stream()))
+    return out
 
 
 def rotate_clouds(points, lens_dev, rot, transpose=False):

@@ -42,12 +42,9 @@ def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_gr
     u = np.vstack([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
     alpha = np.random.rand(B) * 2 * np.pi
     R = create_3D_rotations(u.T, alpha).astype(np.float32)
-    R_dev = torch.from_numpy(R).to(points.device)
-    lens_dev = torch.from_numpy(lens).to(points.device)
-    rotated = ops.rotate_clouds(points, lens_dev, R_dev)
+    rotated = ops.rotate_clouds_host(points, lens, R)
     s_points, s_len = ops.grid_subsample(rotated, lens, sampleDl, max_p=max_p)
-    s_len_dev = torch.from_numpy(s_len).to(points.device)
-    s_points = ops.rotate_clouds(s_points, s_len_dev, R_dev, transpose=True)
+    s_points = ops.rotate_clouds_host(s_points, s_len, R, transpose=True)
     return s_points, s_len
 
 
@@ -116,7 +113,7 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
         input_neighbors.append(conv_i)
         input_pools.append(pool_i)
         input_upsamples.append(up_i)
-        input_lengths.append(torch.from_numpy(np.ascontiguousarray(lens)).to(dev))
+        input_lengths.append(np.ascontiguousarray(lens))
         stacked_points, lens = pool_p, pool_b
         r_normal *= 2
         layer_blocks = []
@@ -125,6 +122,10 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
     if deferred is not None:
         for (lst, pos), mat in zip(slots, deferred.finish()):
             lst[pos] = mat
+    # the per-layer lengths go to the device in ONE copy (views of it are handed out)
+    sizes = [len(a) for a in input_lengths]
+    all_lens = torch.from_numpy(np.concatenate(input_lengths).astype(np.int32)).to(dev)
+    input_lengths = list(torch.split(all_lens, sizes))
     return (input_points + input_neighbors + input_pools + input_upsamples + input_lengths
             + [stacked_features, labels])
 
