@@ -125,7 +125,7 @@ def main():
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (% only matters for gloo rehearsals)
     torch.cuda.set_device(dev)
 
     wl = synthetic.WORKLOADS[args.workload]

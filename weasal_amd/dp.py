@@ -19,7 +19,8 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # WEASAL_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)
+            backend = os.environ.get("WEASAL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
