@@ -119,3 +119,16 @@ def test_kpfcnn_state_dict_keys_match_reference():
     assert ours == ref
     # optimizer split of utils/trainer_PseudoLabel.py:80-81
     assert not [k for k, _ in net.named_parameters() if 'offset' in k]
+
+
+def test_calibration_percentiles():
+    """limits = smallest width leaving 90 % of the rows uncropped (DALES_PseudoLabel.py:1321-1324)"""
+    from weasal_amd.calibration import histogram_size, limits_from_histograms
+    from weasal_amd.config import DALESPLConfig
+    assert histogram_size(DALESPLConfig()) == int(np.ceil(4 / 3 * np.pi * 6.0 ** 3))
+    rng = np.random.default_rng(0)
+    counts = [rng.integers(5, 60, size=4000), rng.integers(20, 90, size=700)]
+    hists = np.vstack([np.bincount(c, minlength=120)[:120] for c in counts])
+    lim = limits_from_histograms(hists, 0.9)
+    for c, l in zip(counts, lim):
+        assert (c <= l).mean() >= 0.9 and (c <= l - 1).mean() < 0.9

@@ -74,3 +74,21 @@ def test_kpfcnn_step_vs_golden(gpu):
     for k in g8.files:
         if k.startswith("sd1/"):
             assert rel(sd1[k[4:]].cpu().numpy(), g8[k]) < 1e-4, k
+
+
+def test_calibrator_on_unlimited_pyramid(gpu):
+    """device histograms == numpy histograms of the same un-limited pyramid (CPU oracle)"""
+    from oracle import pyramid_ref
+    from weasal_amd import calibration, pyramid, synthetic
+    cfg = _cfg()
+    pts, feats, labels, lens = synthetic.make_inputs(3, 2, 1500, 2.5, cfg.in_features_dim)
+    np.random.seed(11)
+    batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu),
+                                torch.from_numpy(labels).to(gpu), lens, ())
+    cal = calibration.NeighborhoodCalibrator(cfg).update(batch)
+    np.random.seed(11)
+    li = pyramid_ref.segmentation_inputs(cfg, pts, feats, labels, lens, ())
+    L = cfg.num_layers
+    want = np.vstack([np.bincount((m < m.shape[0]).sum(1), minlength=cal.hist_n)[:cal.hist_n] for m in li[L:2 * L]])
+    assert np.array_equal(cal.hists.cpu().numpy(), want)
+    assert np.array_equal(cal.limits(), calibration.limits_from_histograms(want, 0.9))
