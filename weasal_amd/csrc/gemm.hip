@@ -46,7 +46,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ p, int64_t
 // Y[M,N] = X[M,K] * B[K,N].  Workgroup = 4 waves = 128 rows x (32*NT) columns; wave w owns rows
 // 32w..32w+31 and NT accumulator tiles.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int BKX>
 __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ x, int64_t m, int k, int64_t ldx,
                                                        const float* __restrict__ b, int n, int64_t ldb,
                                                        float* __restrict__ y, int64_t ldy, int vecx, int vecb,
@@ -54,54 +54,57 @@ __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ 
                                                        int64_t ldr, int act, float slope)
 {
     constexpr int BN = 32 * NT;
-    __shared__ float Xs[BM][BK + 1];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][BN];
+    __shared__ float Xs[BM][BKX + 1];
+    __shared__ __attribute__((aligned(16))) float Bs[BKX][BN];
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int xr = t >> 3, xc = (t & 7) * 4;            // X tile: rows xr + 32 i, cols xc..xc+3
-    constexpr int BPT = (BK * BN / 4 + 255) / 256;       // float4 of the B tile per thread
+    constexpr int XCOLS4 = BKX / 4;                      // float4 per X-tile row
+    constexpr int XROWS = 256 / XCOLS4;                  // rows covered by one pass of the 256 threads
+    constexpr int XPT = BM / XROWS;                      // passes
+    const int xr = t / XCOLS4, xc = (t % XCOLS4) * 4;    // X tile: rows xr + XROWS i, cols xc..xc+3
+    constexpr int BPT = (BKX * BN / 4 + 255) / 256;      // float4 of the B tile per thread
     f32x16 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    float4 xv[4], bv[BPT];
+    float4 xv[XPT], bv[BPT];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = ld4_guard(x, m0 + xr + 32 * i, m, k0 + xc, k, ldx, vecx);
+        for (int i = 0; i < XPT; ++i) xv[i] = ld4_guard(x, m0 + xr + XROWS * i, m, k0 + xc, k, ldx, vecx);
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const int idx = t + 256 * i;
             const int br = idx / (BN / 4), bc = (idx % (BN / 4)) * 4;
-            bv[i] = (br < BK) ? ld4_guard(b, k0 + br, k, n0 + bc, n, ldb, vecb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[i] = (br < BKX) ? ld4_guard(b, k0 + br, k, n0 + bc, n, ldb, vecb) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float* d = &Xs[xr + 32 * i][xc];
+        for (int i = 0; i < XPT; ++i) {
+            float* d = &Xs[xr + XROWS * i][xc];
             d[0] = xv[i].x; d[1] = xv[i].y; d[2] = xv[i].z; d[3] = xv[i].w;
         }
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const int idx = t + 256 * i;
             const int br = idx / (BN / 4), bc = (idx % (BN / 4)) * 4;
-            if (br < BK) *reinterpret_cast<float4*>(&Bs[br][bc]) = bv[i];
+            if (br < BKX) *reinterpret_cast<float4*>(&Bs[br][bc]) = bv[i];
         }
     };
 
     load_tiles(0);
     const int ai = wave * 32 + (lane & 31), kk = lane >> 5, bj = lane & 31;
-    for (int k0 = 0; k0 < k; k0 += BK) {
+    for (int k0 = 0; k0 < k; k0 += BKX) {
         store_tiles();
         __syncthreads();
-        if (k0 + BK < k) load_tiles(k0 + BK);      // in flight under the MFMAs below
+        if (k0 + BKX < k) load_tiles(k0 + BKX);    // in flight under the MFMAs below
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
+        for (int s = 0; s < BKX / 2; ++s) {
             const float a = Xs[ai][2 * s + kk];
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
@@ -300,15 +303,20 @@ int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const
     const int64_t gx = ws_ceil_div(m, BM);
     WS_REQUIRE(gx < (1ll << 31), "m too large");
     if (n <= 32) {
-        gemm_xb_kernel<1><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
+        gemm_xb_kernel<1, 32><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
                                                                  act, slope);
     } else if (n <= 64) {
-        gemm_xb_kernel<2><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
+        gemm_xb_kernel<2, 32><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
                                                                  act, slope);
     } else {
-        gemm_xb_kernel<4><<<dim3((unsigned)gx, (unsigned)ws_ceil_div(n, 128)), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy,
-                                                                                            vecx, vecb, bias, residual, ldr,
-                                                                                            act, slope);
+        // measured (tools/gemm_bench.py, M = 400k): shallow K is latency bound and prefers the 64-column
+        // tile (more waves per SIMD, L2 serves the X re-read); deep K prefers the 128-column tile (X reuse)
+        if (k < 128)
+            gemm_xb_kernel<2, 32><<<dim3((unsigned)gx, (unsigned)ws_ceil_div(n, 64)), 256, 0, st>>>(
+                x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr, act, slope);
+        else
+            gemm_xb_kernel<4, 32><<<dim3((unsigned)gx, (unsigned)ws_ceil_div(n, 128)), 256, 0, st>>>(
+                x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr, act, slope);
     }
     WS_LAUNCH_CHECK();
     return WS_OK;
