@@ -1,0 +1,134 @@
+"""GPU: shapes off the fast paths -- odd channel counts (scalar row pieces), more than 64 / 128
+neighbour columns (several column chunks, the wide sort slab), dense influence modes (entry-pool
+overflow -> sub-chunk redo), empty batch elements, many batch elements -- against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sphere
+from oracle import geom, kpconv_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("ci,h,influence,aggregation", [(6, 130, "linear", "sum"), (5, 40, "constant", "sum"),
+                                                        (20, 70, "gaussian", "sum"), (32, 64, "constant", "closest"),
+                                                        (1, 17, "linear", "sum"), (48, 200, "linear", "sum"),
+                                                        (64, 96, "constant", "sum")])
+def test_kpconv_odd_shapes_vs_torch_restatement(gpu, ci, h, influence, aggregation):
+    from weasal_amd import ops
+    rng = np.random.default_rng(ci * 1000 + h)
+    n = 700
+    pts = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    inds = rng.integers(0, n + 1, size=(n, h))                 # includes shadow entries
+    inds[::9, -3:] = n
+    kp = (rng.normal(size=(15, 3)) * 0.4).astype(np.float32)
+    x = rng.normal(size=(n, ci)).astype(np.float32)
+    dy = rng.normal(size=(n, 15, ci)).astype(np.float32)
+    ext = 0.9
+    t = lambda a: torch.from_numpy(a)
+    xc = t(x).requires_grad_(True)
+    want, _ = kpconv_ref.kpconv_gather_ref(xc, t(pts), t(pts), t(inds), t(kp), ext, influence, aggregation)
+    (want * t(dy)).sum().backward()
+    xg = t(x).to(gpu).requires_grad_(True)
+    got, _ = ops.kpconv_gather(xg, t(pts).to(gpu), t(pts).to(gpu), t(inds).to(gpu), t(kp).to(gpu), ext, influence, aggregation)
+    (got * t(dy).to(gpu)).sum().backward()
+    assert rel(got, want) < 1e-4
+    assert rel(xg.grad, xc.grad) < 1e-4
+
+
+def test_kpconv_different_query_and_support_sets(gpu):
+    from weasal_amd import ops
+    rng = np.random.default_rng(5)
+    nq, ns, h, ci = 333, 901, 33, 12
+    q = rng.uniform(-1, 1, size=(nq, 3)).astype(np.float32)
+    s = rng.uniform(-1, 1, size=(ns, 3)).astype(np.float32)
+    inds = rng.integers(0, ns + 1, size=(nq, h))
+    kp = (rng.normal(size=(15, 3)) * 0.4).astype(np.float32)
+    x = rng.normal(size=(ns, ci)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a)
+    xc = t(x).requires_grad_(True)
+    want, _ = kpconv_ref.kpconv_gather_ref(xc, t(q), t(s), t(inds), t(kp), 0.8)
+    want.square().sum().backward()
+    xg = t(x).to(gpu).requires_grad_(True)
+    got, _ = ops.kpconv_gather(xg, t(q).to(gpu), t(s).to(gpu), t(inds).to(gpu), t(kp).to(gpu), 0.8)
+    got.square().sum().backward()
+    assert rel(got, want) < 1e-4 and rel(xg.grad, xc.grad) < 1e-4
+
+
+def test_neighbors_dense_rows_over_128(gpu):
+    """rows of ~300 neighbours: wide sort slab, and the deferred search repeats itself synchronously"""
+    from weasal_amd import ops
+    rng = np.random.default_rng(8)
+    p = sphere(rng, 3000, 1.0)
+    lens = np.array([3000], np.int32)
+    want = geom.batch_query(p, p, lens, lens, 0.5)
+    assert want.shape[1] > 128
+    P = torch.from_numpy(p).to(gpu)
+    got = ops.radius_neighbors(P, P, lens, lens, 0.5, dtype=torch.int32).cpu().numpy()
+    assert np.array_equal(got, want)
+    got = ops.radius_neighbors(P, P, lens, lens, 0.5, limit=200, dtype=torch.int64).cpu().numpy()
+    assert np.array_equal(got, want[:, :200])
+    d = ops.DeferredSearches(gpu)
+    d.add(P, P, lens, lens, 0.5, 150)
+    d.add(P, P, lens, lens, 0.05, 150)        # few neighbours: trimmed to the true width
+    a, b = d.finish()
+    assert np.array_equal(a.cpu().numpy(), want[:, :150])
+    assert np.array_equal(b.cpu().numpy(), geom.batch_query(p, p, lens, lens, 0.05).astype(np.int64))
+
+
+def test_empty_and_many_batch_elements(gpu):
+    from weasal_amd import ops
+    rng = np.random.default_rng(9)
+    # an empty element in the middle
+    p = np.concatenate([sphere(rng, 900, 2.0), sphere(rng, 700, 2.0, (0.3, 0, 0))])
+    lens = np.array([900, 0, 700], np.int32)
+    P = torch.from_numpy(p).to(gpu)
+    want = geom.batch_query(p, p, lens, lens, 0.5)
+    assert np.array_equal(ops.radius_neighbors(P, P, lens, lens, 0.5, dtype=torch.int32).cpu().numpy(), want)
+    wp, wl = geom.subsample_batch(p, lens, sampleDl=0.4)
+    gp, gl = ops.grid_subsample(P, lens, 0.4)
+    assert np.array_equal(gl, wl) and np.array_equal(gp.cpu().numpy(), wp)
+    # 70 small elements (beyond the 48 / 64 entry kernel-argument tables)
+    sizes = rng.integers(20, 60, size=70).astype(np.int32)
+    p = np.concatenate([sphere(rng, int(n), 1.0, (0.01 * i, 0, 0)) for i, n in enumerate(sizes)])
+    P = torch.from_numpy(p).to(gpu)
+    want = geom.batch_query(p, p, sizes, sizes, 0.4)
+    assert np.array_equal(ops.radius_neighbors(P, P, sizes, sizes, 0.4, dtype=torch.int32).cpu().numpy(), want)
+    wp, wl = geom.subsample_batch(p, sizes, sampleDl=0.3)
+    gp, gl = ops.grid_subsample(P, sizes, 0.3)
+    assert np.array_equal(gl, wl) and np.array_equal(gp.cpu().numpy(), wp)
+    R = rng.normal(size=(70, 3, 3)).astype(np.float32)
+    a = ops.rotate_clouds_host(P, sizes, R).cpu().numpy()
+    b = ops.rotate_clouds(P, torch.from_numpy(sizes).to(gpu), torch.from_numpy(R).to(gpu)).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("c", [5, 24, 100, 300])
+def test_pools_odd_channels(gpu, c):
+    from weasal_amd import ops
+    rng = np.random.default_rng(c)
+    ns, nq, h = 500, 260, 21
+    x = rng.normal(size=(ns, c)).astype(np.float32)
+    inds = rng.integers(0, ns + 1, size=(nq, h))
+    dy = rng.normal(size=(nq, c)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a)
+    xc = t(x).requires_grad_(True)
+    want = kpconv_ref.max_pool_ref(xc, t(inds))
+    (want * t(dy)).sum().backward()
+    xg = t(x).to(gpu).requires_grad_(True)
+    got = ops.max_pool(xg, t(inds).to(gpu))
+    (got * t(dy).to(gpu)).sum().backward()
+    assert torch.equal(got.detach().cpu(), want.detach()) and rel(xg.grad, xc.grad) < 1e-6
+    xc2 = t(x).requires_grad_(True)
+    w2 = kpconv_ref.closest_pool_ref(xc2, t(inds))
+    (w2 * t(dy)).sum().backward()
+    xg2 = t(x).to(gpu).requires_grad_(True)
+    g2 = ops.closest_pool(xg2, t(inds).to(gpu))
+    (g2 * t(dy).to(gpu)).sum().backward()
+    assert torch.equal(g2.detach().cpu(), w2.detach()) and rel(xg2.grad, xc2.grad) < 1e-6
