@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--blas", default="", help="torch.backends.cuda.preferred_blas_library (A/B only)")
+    ap.add_argument("--prefetch", type=int, default=1,
+                    help="1: build the pyramid of the next batches on a second HIP stream / host thread while the "
+                         "current step trains (weasal_amd.prefetch, the GPU counterpart of the reference's DataLoader "
+                         "workers); 0: pyramid and training strictly one after the other on one stream")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -152,9 +156,23 @@ def main():
     timer = KernelTimer()
     ops.set_kernel_timer(timer)
 
+    prefetcher = None
+    if args.prefetch:
+        from weasal_amd.prefetch import PyramidPrefetcher
+
+        def endless():
+            i = 0
+            while True:
+                yield inputs[i % nd]
+                i += 1
+        prefetcher = PyramidPrefetcher(cfg, endless(), wl["limits"], depth=2, device=dev)
+
     def step(i):
-        pts, feats, labels, lens = inputs[i % nd]
-        batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
+        if prefetcher is not None:
+            batch = next(prefetcher)
+        else:
+            pts, feats, labels, lens = inputs[i % nd]
+            batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
         loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync)
         return loss
 
@@ -184,6 +202,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    if prefetcher is not None:
+        prefetcher.close()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,7 +217,8 @@ def main():
                "host_issue_ms_per_step": 1000.0 * t_enqueued / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl["name"] + ", fp32, step = GPU pyramid + fwd + loss + bwd"
-                          + (" + RCCL grad all-reduce" if world > 1 else "") + " + SGD",
+                          + (" + RCCL grad all-reduce" if world > 1 else "") + " + SGD"
+                          + ("; pyramid of the next batch overlapped on a second stream" if args.prefetch else ""),
                           "points_per_step_per_gpu": n_points, "parallelism": "dp%d" % world,
                           "final_loss": float(loss.item())}}
         # ---- roofline of the fused KPConv gather kernel on the largest layer

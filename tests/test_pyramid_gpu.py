@@ -92,3 +92,40 @@ def test_calibrator_on_unlimited_pyramid(gpu):
     want = np.vstack([np.bincount((m < m.shape[0]).sum(1), minlength=cal.hist_n)[:cal.hist_n] for m in li[L:2 * L]])
     assert np.array_equal(cal.hists.cpu().numpy(), want)
     assert np.array_equal(cal.limits(), calibration.limits_from_histograms(want, 0.9))
+
+
+def test_prefetcher_matches_direct_build(gpu):
+    """batches built ahead on the side stream == batches built in line (same np.random stream), and a
+    training step on a prefetched batch gives the same loss"""
+    from weasal_amd import pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    from weasal_amd.prefetch import PyramidPrefetcher
+    from weasal_amd.trainer import make_optimizer, train_step
+    cfg = _cfg()
+    raw = []
+    for i in range(3):
+        p, f, l, le = synthetic.make_inputs(50 + i, 2, 1200, 2.5, cfg.in_features_dim)
+        raw.append((torch.from_numpy(p).to(gpu), torch.from_numpy(f).to(gpu), torch.from_numpy(l).to(gpu), le))
+    limits = [20, 24, 26, 26, 20]
+    np.random.seed(77)
+    direct = [pyramid.build_batch(cfg, *r, limits) for r in raw]
+    torch.cuda.synchronize()
+    np.random.seed(77)
+    pf = PyramidPrefetcher(cfg, iter(raw), limits, depth=2, device=gpu)
+    got = list(pf)
+    pf.close()
+    assert len(got) == 3
+    for a, b in zip(got, direct):
+        a.activate()
+        for name in ("points", "neighbors", "pools", "upsamples", "lengths"):
+            for x, y in zip(getattr(a, name), getattr(b, name)):
+                assert torch.equal(x, y), name
+        assert len(a.point_orders) == len(b.point_orders) == 5
+    losses = []
+    for batches in (direct, got):
+        np.random.seed(3); torch.manual_seed(3)
+        net = KPFCNN(cfg, np.arange(9), []).to(gpu).train()
+        opt = make_optimizer(net, cfg)
+        out = [train_step(net, opt, bt, cfg)[0].item() for bt in batches]
+        losses.append(out)
+    assert np.allclose(losses[0], losses[1], rtol=1e-5, atol=1e-6)

@@ -119,6 +119,9 @@ class KPFCNN(nn.Module):
                                    slope=None if unary.no_relu else 0.1)
 
     def forward(self, batch, config):
+        if hasattr(batch, "activate"):
+            batch.activate()                 # stream hand-over + scheduling hints of a prefetched batch
+            ops.clear_table_cache()          # transposed tables belong to one batch
         x = batch.features.clone().detach()
         skips = []
         for block_i, block_op in enumerate(self.encoder_blocks):

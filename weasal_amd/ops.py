@@ -108,6 +108,14 @@ def clear_point_orders():
     _orders.clear()
 
 
+def set_point_orders(pairs):
+    """install the (points, order) pairs of the batch that is about to be trained on
+    (PyramidBatch.point_orders); replaces whatever the previous batch registered"""
+    _orders.clear()
+    for points, order in pairs:
+        _orders[points.data_ptr()] = order
+
+
 def _order_for(points):
     o = _orders.get(points.data_ptr())
     if o is not None and o.numel() == points.shape[0] and o.device == points.device:

@@ -20,15 +20,9 @@ from . import ops
 from .kernel_points import create_3D_rotations
 
 
-def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None, register_order=False):
-    """device form of datasets/common.py:185-196 (+ the crop of :336-346 and the int64 cast of :551).
-    register_order: remember the supports' cell order as the scheduling order of that point set."""
-    if not register_order:
-        return ops.radius_neighbors(queries, supports, q_batches, s_batches, radius, limit=limit, dtype=torch.int64)
-    inds, order = ops.radius_neighbors(queries, supports, q_batches, s_batches, radius, limit=limit,
-                                       dtype=torch.int64, return_order=True)
-    ops.register_point_order(supports, order)
-    return inds
+def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None):
+    """device form of datasets/common.py:185-196 (+ the crop of :336-346 and the int64 cast of :551)"""
+    return ops.radius_neighbors(queries, supports, q_batches, s_batches, radius, limit=limit, dtype=torch.int64)
 
 
 def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_grid_orient=True):
@@ -49,7 +43,7 @@ def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_gr
 
 
 def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_lengths,
-                        neighborhood_limits=(), random_grid_orient=True):
+                        neighborhood_limits=(), random_grid_orient=True, point_orders=None):
     """-> flat list  points[L] + neighbors[L] + pools[L] + upsamples[L] + lengths[L] + [features, labels]
     (datasets/common.py:574-575), all device tensors (lengths int32, indices int64).
 
@@ -58,8 +52,7 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
     limits every search needs its width on the host first (two-call protocol)."""
     dev = stacked_points.device
     stacked_points = stacked_points.detach().to(torch.float32).contiguous()
-    ops.clear_point_orders()
-    ops.clear_table_cache()      # transposed tables belong to one batch: keep the footprint per step constant
+    orders = [] if point_orders is None else point_orders     # (points, cell order) per layer: scheduling hints
     lens = np.asarray(stack_lengths.cpu() if isinstance(stack_lengths, torch.Tensor) else stack_lengths, dtype=np.int32)
     r_normal = config.first_subsampling_dl * config.conv_radius
     limits = list(neighborhood_limits)
@@ -68,10 +61,14 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
 
     def search(q, s, ql, sl, r, layer, register_order=False):
         if deferred is None:
-            return batch_neighbors(q, s, ql, sl, r, None, register_order=register_order)
+            if not register_order:
+                return ops.radius_neighbors(q, s, ql, sl, r, dtype=torch.int64)
+            inds, order = ops.radius_neighbors(q, s, ql, sl, r, dtype=torch.int64, return_order=True)
+            orders.append((s, order))
+            return inds
         if register_order:
             inds, order = deferred.add(q, s, ql, sl, r, limits[layer], want_order=True)
-            ops.register_point_order(s, order)
+            orders.append((s, order))
             return inds
         return deferred.add(q, s, ql, sl, r, limits[layer])
 
@@ -133,10 +130,12 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
 class PyramidBatch:
     """The `batch` object the blocks index (``.points/.neighbors/.pools/.upsamples/.lengths/
     .features/.labels``), built from the flat list like the reference's CustomBatch classes
-    (datasets/DALES_PseudoLabel.py:1386-1460)."""
+    (datasets/DALES_PseudoLabel.py:1386-1460; a list that also carries the five bookkeeping arrays
+    scales, rots, cloud_inds, center_inds, input_inds of :1410-1421 is accepted too)."""
 
-    def __init__(self, input_list):
-        L = (len(input_list) - 2) // 5
+    def __init__(self, input_list, point_orders=()):
+        extra = 7 if (len(input_list) - 7) % 5 == 0 and (len(input_list) - 2) % 5 != 0 else 2
+        L = (len(input_list) - extra) // 5
         self.points = list(input_list[0:L])
         self.neighbors = list(input_list[L:2 * L])
         self.pools = list(input_list[2 * L:3 * L])
@@ -144,12 +143,27 @@ class PyramidBatch:
         self.lengths = list(input_list[4 * L:5 * L])
         self.features = input_list[5 * L]
         self.labels = input_list[5 * L + 1]
+        if extra == 7:
+            self.scales, self.rots, self.cloud_inds, self.center_inds, self.input_inds = input_list[5 * L + 2:5 * L + 7]
+        self.point_orders = list(point_orders)   # [(points tensor, cell-order permutation)]: scheduling hints
+        self.ready = None                        # event recorded on the stream that built the batch
+
+    def _tensors(self):
+        for name in ("points", "neighbors", "pools", "upsamples", "lengths"):
+            yield from getattr(self, name)
+        yield self.features
+        yield self.labels
+        for _, o in self.point_orders:
+            yield o
 
     def _map(self, fn):
         for name in ("points", "neighbors", "pools", "upsamples", "lengths"):
             setattr(self, name, [fn(t) for t in getattr(self, name)])
         self.features = fn(self.features)
         self.labels = fn(self.labels)
+        for name in ("scales", "rots", "cloud_inds", "center_inds", "input_inds"):
+            if hasattr(self, name):
+                setattr(self, name, fn(getattr(self, name)))
         return self
 
     def to(self, device):
@@ -158,7 +172,28 @@ class PyramidBatch:
     def pin_memory(self):
         return self._map(lambda t: t.pin_memory())
 
+    def activate(self, stream=None):
+        """Make the batch usable on `stream` (default: the current one): wait for the stream that built
+        it, tell the caching allocator about the second user, install the scheduling orders.  Called by
+        KPFCNN.forward; a no-op for batches built on the same stream."""
+        if self.features.is_cuda:
+            stream = stream or torch.cuda.current_stream(self.features.device)
+            if self.ready is not None:
+                stream.wait_event(self.ready)
+                for t in self._tensors():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(stream)
+                self.ready = None
+            ops.set_point_orders(self.point_orders)
+        return self
+
 
 def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True):
-    return PyramidBatch(segmentation_inputs(config, points, features, labels, lengths, neighborhood_limits,
-                                            random_grid_orient))
+    orders = []
+    li = segmentation_inputs(config, points, features, labels, lengths, neighborhood_limits, random_grid_orient,
+                             point_orders=orders)
+    batch = PyramidBatch(li, orders)
+    if points.is_cuda:
+        batch.ready = torch.cuda.Event()
+        batch.ready.record(torch.cuda.current_stream(points.device))
+    return batch
