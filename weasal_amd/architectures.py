@@ -120,7 +120,8 @@ class KPFCNN(nn.Module):
 
     def forward(self, batch, config):
         if hasattr(batch, "activate"):
-            batch.activate()                 # stream hand-over + scheduling hints of a prefetched batch
+            batch.activate()     # stream hand-over, scheduling hints and pre-built tables of the batch
+        else:
             ops.clear_table_cache()          # transposed tables belong to one batch
         x = batch.features.clone().detach()
         skips = []

@@ -91,6 +91,19 @@ def transposed_table(inds, ns):
 
 def clear_table_cache():
     _tables.clear()
+    _col0_tables.clear()
+
+
+_col0_tables = {}     # (inds.data_ptr(), shape, ns) -> table of the first column (closest_pool backward)
+
+
+def install_tables(full, col0):
+    """pre-built tables of a prefetched batch (PyramidBatch.activate): `full` = [(inds, ns, table)],
+    `col0` = [(inds, ns, table of inds[:, :1])]"""
+    for inds, ns, table in full:
+        _tables[(inds.data_ptr(), tuple(inds.shape), ns, inds._version)] = (inds, table)
+    for inds, ns, table in col0:
+        _col0_tables[(inds.data_ptr(), tuple(inds.shape), ns)] = (inds, table)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -364,17 +377,25 @@ class _ClosestPool(torch.autograd.Function):
         check(lib.ws_closest_pool_fwd(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), current_stream()))
         # only the first column takes part (blocks.py:92): the backward needs the transposed
         # table of that column alone (lists of ~N_fine/N_coarse entries instead of ~H times that)
-        ctx.col0 = inds[:, :1].contiguous()
+        ctx.key = (inds.data_ptr(), tuple(inds.shape), ns)
+        ctx.col0 = None if ctx.key in _col0_tables else inds[:, :1].contiguous()
+        ctx.nq = nq
         ctx.ns = ns
         return out
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.lib()
-        col0 = ctx.col0
-        nq = col0.shape[0]
+        nq = ctx.nq
         c = dy.shape[1]
-        table = TransposedTable(col0, ctx.ns)
+        hit = _col0_tables.get(ctx.key)
+        if hit is not None:
+            table = hit[1]
+        else:
+            col0 = ctx.col0 if ctx.col0 is not None else None
+            if col0 is None:
+                raise _lib.WeasalHipError("closest_pool backward: the pre-built column-0 table was dropped before backward")
+            table = TransposedTable(col0, ctx.ns)
         dx = torch.empty((ctx.ns, c), dtype=torch.float32, device=dy.device)
         dy = dy.contiguous()
         check(lib.ws_closest_pool_bwd(ptr(dy), nq, 1, c, ptr(table.offsets), ptr(table.pairs), ctx.ns, ptr(dx),

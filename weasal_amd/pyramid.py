@@ -146,6 +146,8 @@ class PyramidBatch:
         if extra == 7:
             self.scales, self.rots, self.cloud_inds, self.center_inds, self.input_inds = input_list[5 * L + 2:5 * L + 7]
         self.point_orders = list(point_orders)   # [(points tensor, cell-order permutation)]: scheduling hints
+        self.tables = []                         # pre-built transposed tables [(inds, ns, table)] (build_tables)
+        self.col0_tables = []
         self.ready = None                        # event recorded on the stream that built the batch
 
     def _tensors(self):
@@ -155,6 +157,26 @@ class PyramidBatch:
         yield self.labels
         for _, o in self.point_orders:
             yield o
+        for _, _, tb in self.tables + self.col0_tables:
+            yield tb.offsets
+            yield tb.pairs
+
+    def build_tables(self):
+        """Transposed neighbour tables every backward of this batch needs (KPConv dX over neighbors[l] /
+        pools[l], max_pool over pools[l], closest_pool over column 0 of upsamples[l]); built here -- on the
+        stream that builds the batch -- they are off the training stream's critical path."""
+        self.tables, self.col0_tables = [], []
+        L = len(self.points)
+        for l in range(L):
+            ns = self.points[l].shape[0]
+            for mat in (self.neighbors[l], self.pools[l]):
+                if mat.shape[0] > 0 and mat.is_cuda:
+                    self.tables.append((mat, ns, ops.TransposedTable(mat, ns)))
+            up = self.upsamples[l]
+            if up.shape[0] > 0 and up.is_cuda and l + 1 < L:
+                nc = self.points[l + 1].shape[0]
+                self.col0_tables.append((up, nc, ops.TransposedTable(up[:, :1].contiguous(), nc)))
+        return self
 
     def _map(self, fn):
         for name in ("points", "neighbors", "pools", "upsamples", "lengths"):
@@ -185,14 +207,19 @@ class PyramidBatch:
                         t.record_stream(stream)
                 self.ready = None
             ops.set_point_orders(self.point_orders)
+            ops.clear_table_cache()              # tables belong to one batch
+            ops.install_tables(self.tables, self.col0_tables)
         return self
 
 
-def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True):
+def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True,
+                with_tables=True):
     orders = []
     li = segmentation_inputs(config, points, features, labels, lengths, neighborhood_limits, random_grid_orient,
                              point_orders=orders)
     batch = PyramidBatch(li, orders)
+    if with_tables and points.is_cuda:
+        batch.build_tables()
     if points.is_cuda:
         batch.ready = torch.cuda.Event()
         batch.ready.record(torch.cuda.current_stream(points.device))
