@@ -132,6 +132,184 @@ __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ 
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// shared float4 epilogue of the rows-on-lanes kernels: lane = row, register quad g of tile i = columns
+// n0 + 32 i + 8 g + 4 h .. + 3.  Residual quads are loaded with clamped columns (no control flow around
+// the loads, so they are all in flight together); only the stores are predicated.
+template <int NT>
+__device__ __forceinline__ void xb_rows_epilogue(const f32x16 (&acc)[NT], int64_t row, int64_t m, int n0, int n, int h,
+                                                 float* __restrict__ y, int64_t ldy, const float* __restrict__ bias,
+                                                 const float* __restrict__ residual, int64_t ldr, int act, float slope)
+{
+    const bool live = row < m;
+    const int64_t rr = live ? row : m - 1;
+    float* yrow = y + rr * ldy;
+    const float* rrow = residual ? residual + rr * ldr : nullptr;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        float4 v[4];
+        int col[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            col[g] = n0 + 32 * i + 8 * g + 4 * h;
+            v[g] = make_float4(acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        }
+        if (rrow) {
+            float4 rq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rq[g] = *reinterpret_cast<const float4*>(rrow + (col[g] < n ? col[g] : n - 4));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { v[g].x += rq[g].x; v[g].y += rq[g].y; v[g].z += rq[g].z; v[g].w += rq[g].w; }
+        }
+        if (bias) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + (col[g] < n ? col[g] : n - 4));
+                v[g].x += bq.x; v[g].y += bq.y; v[g].z += bq.z; v[g].w += bq.w;
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v[g].x = v[g].x > 0.0f ? v[g].x : v[g].x * slope;
+                v[g].y = v[g].y > 0.0f ? v[g].y : v[g].y * slope;
+                v[g].z = v[g].z > 0.0f ? v[g].z : v[g].z * slope;
+                v[g].w = v[g].w > 0.0f ? v[g].w : v[g].w * slope;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (live && col[g] < n) *reinterpret_cast<float4*>(yrow + col[g]) = v[g];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_xb2: same product, "rows on the lanes".  The MFMA is fed transposed: A operand = the small
+// matrix (i = output column), B operand = X (j = row of X), so that
+//   * X never goes through LDS: lane (idx, h) reads float4 X[row idx][k0 + 8j + 4h ..] straight into
+//     the B-operand registers (a row's 128-byte line is consumed by 4 consecutive loads of one wave);
+//     MFMA step (j, e) contracts k = k0 + 8j + 4h + e, the two wave halves supplying two different k;
+//   * the small matrix chunk [32 x BN] is staged in LDS already interleaved as Ws[t][j][h][idx][e], so
+//     one conflict-free ds_read_b128 feeds four MFMAs; double buffered: ONE barrier per 32-deep chunk;
+//   * a lane ends up with 4 consecutive output columns of its own row per register quad: the epilogue
+//     is float4 (bias, residual, LeakyReLU, store) instead of 16 scalar stores per tile.
+// Workgroup = 4 waves, wave w owns RT row tiles of 32 rows, all waves share the W chunk.
+// ---------------------------------------------------------------------------------------------
+// Preconditions (checked by the launcher; everything else takes gemm_xb_kernel): k % 32 == 0, n % 4 == 0,
+// x / y / residual rows 16-byte aligned.  Rows past m and columns past n are clamped on the loads
+// (valid memory, results never stored), so the main loop has no divergent control flow at all.
+template <int NT, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_xb2_kernel(
+    const float* __restrict__ x, int64_t m, int k, int64_t ldx, const float* __restrict__ b, int n, int ldb,
+    float* __restrict__ y, int64_t ldy, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldr,
+    int act, float slope)
+{
+    constexpr int WM = 4 / WN;                            // wave grid WM x WN: rows x column groups
+    constexpr int CT = NT * WN;                           // 32-column tiles per workgroup
+    constexpr int BN = 32 * CT;
+    constexpr int KC = 32;
+    constexpr int WBUF = CT * 1024;                       // floats per W chunk buffer
+    __shared__ __attribute__((aligned(16))) float Ws[2 * WBUF];
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lane = t & 63;
+    const int idx = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * (32 * WM) + wm * 32 + idx;
+    const int n0 = blockIdx.y * BN;
+    const int nchunks = k / KC;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    // W staging: group g = t + 256 i -> column c = g % BN, row quad q = g / BN (rows 4q .. 4q+3 of the
+    // chunk) -> one float4 at Ws[tile = c/32][j = q/2][h = q%2][idx = c%32][e = 0..3]
+    // buffer addressing (wave-uniform descriptors from kernel arguments / blockIdx, per-lane constant byte
+    // offsets, the chunk advance in the scalar offset): no vector address arithmetic in the loop; rows of
+    // X past m read as 0 through the bounds check
+    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, (int)((int64_t)k * ldb * 4), 0x00020000);
+    const int64_t brow0 = (int64_t)blockIdx.x * (32 * WM);
+    const int64_t brows = m - brow0 < 32 * WM ? m - brow0 : 32 * WM;
+    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + brow0 * ldx), 0,
+                                                        (int)(((brows - 1) * ldx + k) * 4), 0x00020000);
+    int woff[CT];
+    int wlds[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int g = t + 256 * i;
+        const int c = g % BN, q = g / BN;
+        int col = n0 + c;
+        col = col < n ? col : n - 1;
+        woff[i] = (4 * q * ldb + col) * 4;
+        wlds[i] = ((((c >> 5) * 4 + (q >> 1)) * 2 + (q & 1)) * 32 + (c & 31)) * 4;
+    }
+    float4 wv[CT];
+    auto load_w = [&](int chunk) {
+        const int so = chunk * KC * ldb * 4;                       // uniform byte offset of the chunk
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            wv[i].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrd, woff[i], so, 0));
+            wv[i].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrd, woff[i], so + ldb * 4, 0));
+            wv[i].z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrd, woff[i], so + ldb * 8, 0));
+            wv[i].w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrd, woff[i], so + ldb * 12, 0));
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i) *reinterpret_cast<float4*>(&Ws[buf * WBUF + wlds[i]]) = wv[i];
+    };
+    const int xoff = (int)((wm * 32 + idx) * ldx + 4 * h) * 4;
+    float4 xn[4], xc[4];
+    auto load_x = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xsrd, xoff + 32 * j, chunk * (KC * 4), 0);
+            xn[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    };
+
+    const int last = nchunks - 1;
+    load_w(0);
+    load_x(0);
+    {   // chunk 1 of W goes out before anything waits on chunk 0
+        float4 w0[CT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) w0[i] = wv[i];
+        load_w(last < 1 ? last : 1);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) *reinterpret_cast<float4*>(&Ws[wlds[i]]) = w0[i];
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xc[j] = xn[j];
+        store_w((c + 1) & 1);                                   // chunk c+1 (a harmless repeat after the last one)
+        load_x(c + 1 < last ? c + 1 : last);
+        load_w(c + 2 < last ? c + 2 : last);
+        const float* wb = &Ws[(c & 1) * WBUF + wn * (NT * 1024) + (h * 32 + idx) * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of step j+1 out of step j (registers)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const float4 a4 = *reinterpret_cast<const float4*>(wb + (i * 4 + j) * 256);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, xc[j].x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, xc[j].y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xc[j].z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xc[j].w, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope);
+}
+
 // ---------------------------------------------------------------------------------------------
 // partial[c][K,N] = X[rows of chunk c, K]^T * Y[rows of chunk c, N].  Workgroup = (32*KT) k-rows x
 // (32*NT) columns of the output for one chunk of tall rows.  The 4 waves are KT k-tiles x RG = 4/KT
@@ -250,6 +428,141 @@ __global__ __launch_bounds__(256) void gemm_xty_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_xty2: the same reduction with NO LDS staging.  For O = X^T Y both MFMA operands index the
+// tall dimension with k: lane (idx, h) of a step supplies row r + h of X (A operand, i = X column)
+// and of Y (B operand, j = Y column), so a wave can load its operands straight from global memory in
+// MFMA layout -- lanes 0-31 read 32*KT contiguous floats of one row, lanes 32-63 of the next.
+// A lane loads KT (NT) adjacent columns at once; column c0 + KT*idx + tk belongs to the interleaved
+// tile tk, so one dwordx2 load feeds two tiles.  A wave owns (32 KT) x (32 NT) outputs; the 4 waves
+// of a workgroup are WK x WN tiles x WR row groups (row groups are summed through LDS at the end,
+// fixed order).  Loads run U steps ahead of the MFMAs; no barrier in the main loop.
+// ---------------------------------------------------------------------------------------------
+template <int KT, int NT, int WK, int WN>
+__global__ __launch_bounds__(256) void gemm_xty2_kernel(const float* __restrict__ x, int64_t m, int k, int64_t ldx,
+                                                         const float* __restrict__ yy, int n, int64_t ldy,
+                                                         float* __restrict__ partial, int64_t chunk)
+{
+    constexpr int WR = 4 / (WK * WN);
+    constexpr int U = 8;                                   // steps (row pairs) per block
+    __shared__ float red[(WR > 1) ? WK * WN * KT * NT * 16 * 64 : 1];
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63;
+    const int idx = lane & 31, h = lane >> 5;
+    const int wr = wave / (WK * WN), wk = (wave / WN) % WK, wn = wave % WN;
+    const int c0 = (blockIdx.y * WK + wk) * (32 * KT);
+    const int n0 = (blockIdx.z * WN + wn) * (32 * NT);
+    const int64_t mbeg = (int64_t)blockIdx.x * chunk;
+    const int64_t mend = mbeg + chunk < m ? mbeg + chunk : m;
+
+    f32x16 acc[KT][NT];
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.0f;
+
+    // columns past the end are clamped (their outputs are never stored); rows past the end are clamped
+    // and the A operand zeroed
+    int xc = c0 + KT * idx;
+    xc = xc + KT <= k ? xc : (k - KT > 0 ? k - KT : 0);
+    int yc = n0 + NT * idx;
+    yc = yc + NT <= n ? yc : (n - NT > 0 ? n - NT : 0);
+    // buffer addressing: one descriptor per operand covering this workgroup's rows (wave-uniform: built
+    // from kernel arguments and blockIdx only), per-lane constant byte offset, the row advance in the
+    // scalar offset -> no vector address arithmetic next to the MFMAs, and rows past the end of the
+    // chunk read as 0 through the descriptor's bounds check (no tail code)
+    const int64_t nrows = mend - mbeg;
+    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + mbeg * ldx), 0,
+                                                        (int)(((nrows - 1) * ldx + k) * 4), 0x00020000);
+    const auto ysrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(yy + mbeg * ldy), 0,
+                                                        (int)(((nrows - 1) * ldy + n) * 4), 0x00020000);
+    const int xoff = (int)(h * ldx + xc) * 4, yoff = (int)(h * ldy + yc) * 4;
+    const int xstep = (int)ldx * 8, ystep = (int)ldy * 8;      // bytes per step (two rows)
+    float xa[2][U][KT], ya[2][U][NT];
+    auto load_block = [&](int blk, int slot) {                 // blk = index of the 2U-row block in the chunk (uniform)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int step = blk * U + u;
+            if (KT == 2) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xsrd, xoff, step * xstep, 0);
+                xa[slot][u][0] = __uint_as_float(v.x);
+                xa[slot][u][KT - 1] = __uint_as_float(v.y);
+            } else {
+                xa[slot][u][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xsrd, xoff, step * xstep, 0));
+            }
+            if (NT == 2) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ysrd, yoff, step * ystep, 0);
+                ya[slot][u][0] = __uint_as_float(v.x);
+                ya[slot][u][NT - 1] = __uint_as_float(v.y);
+            } else {
+                ya[slot][u][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ysrd, yoff, step * ystep, 0));
+            }
+        }
+    };
+    auto compute = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[slot][u][a], ya[slot][u][i], acc[a][i], 0, 0, 0);
+    };
+    // row group wr takes blocks wr, wr + WR, ... of 2U rows; two blocks per trip (static register slots)
+    const int nblk = (int)((nrows + 2 * U - 1) / (2 * U));
+    int blk = wr;
+    if (blk < nblk) load_block(blk, 0);
+    for (; blk < nblk; blk += 2 * WR) {
+        if (blk + WR < nblk) load_block(blk + WR, 1);
+        compute(0);
+        if (blk + WR < nblk) {
+            if (blk + 2 * WR < nblk) load_block(blk + 2 * WR, 0);
+            compute(1);
+        }
+    }
+    if (WR > 1) {
+        // sum the row groups in order 1, 2, 3 onto group 0 (layout [wk][wn][a][i][r][lane])
+        const int base = ((wk * WN + wn) * KT * NT) * 16 * 64;
+        for (int src = 1; src < WR; ++src) {
+            if (wr == src) {
+#pragma unroll
+                for (int a = 0; a < KT; ++a)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) red[base + ((a * NT + i) * 16 + r) * 64 + lane] = acc[a][i][r];
+            }
+            __syncthreads();
+            if (wr == 0) {
+#pragma unroll
+                for (int a = 0; a < KT; ++a)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][i][r] += red[base + ((a * NT + i) * 16 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+    }
+    if (wr == 0) {
+        float* out = partial + (int64_t)blockIdx.x * k * n;
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int col = n0 + NT * idx + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = c0 + KT * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
+                    if (row < k && col < n) out[(int64_t)row * n + col] = acc[a][i][r];
+                }
+            }
+    }
+}
+
 // out[e] = sum_c partial[c][e] in a fixed order (bitwise reproducible): 32 elements x 8 chunk groups
 // per workgroup, group g adds chunks g, g+8, ... (coalesced 128-byte reads), then the 8 group sums
 // are added in order.
@@ -288,6 +601,10 @@ int64_t xty_chunk(int64_t m, int k, int n)
 
 extern "C" {
 
+// diagnostic switches of tools/gemm_lab.cpp (not part of the drop-in surface of include/weasal_hip.h)
+int ws_gemm_wave_cols = 0;  // forced wave grid of gemm_xb2 (column groups 1 / 2), 0 = automatic
+int ws_gemm_variant = 2;    // 1 = LDS-staged tiles (gemm_xb / gemm_xty), 2 = operands straight from global memory
+
 int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                         const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
                         float* y, int64_t ldy, void* stream)
@@ -302,6 +619,31 @@ int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const
     const int vecb = al16(b) && (n % 4 == 0);
     const int64_t gx = ws_ceil_div(m, BM);
     WS_REQUIRE(gx < (1ll << 31), "m too large");
+    if (ws_gemm_variant == 2 && vecx && k % 32 == 0 && n % 4 == 0 && al16(y) && ldy % 4 == 0 &&
+        (!residual || (al16(residual) && ldr % 4 == 0)) && (!bias || al16(bias)) && (int64_t)k * n < (1ll << 29) &&
+        128 * ldx < (1ll << 29)) {
+#define WS_XB2(NTV, WNV)                                                                                        \
+    gemm_xb2_kernel<NTV, WNV><<<dim3((unsigned)ws_ceil_div(m, 32 * (4 / WNV)), (unsigned)ws_ceil_div(n, 32 * NTV * WNV)), \
+                                256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, bias, residual, ldr, act, slope)
+        // wave grid: tall operands give every wave its own rows (4 x 1); shorter ones put 2 waves on
+        // the same rows (column groups) so that the launch still fills 256 CUs and the per-wave MFMA
+        // chain k/2 * NT stays short (measured: tools/gemm_lab.cpp)
+        const int64_t tiles = ws_ceil_div(m, 32);
+        int wn = tiles >= 2048 ? 1 : 2;
+        if (ws_gemm_wave_cols) wn = ws_gemm_wave_cols;
+        if (n <= 32) wn = 1;
+        if (wn == 1) {
+            if (n <= 32) WS_XB2(1, 1);
+            else if (n <= 64) WS_XB2(2, 1);
+            else WS_XB2(4, 1);
+        } else {
+            if (n <= 64) WS_XB2(1, 2);
+            else WS_XB2(2, 2);
+        }
+#undef WS_XB2
+        WS_LAUNCH_CHECK();
+        return WS_OK;
+    }
     if (n <= 32) {
         gemm_xb_kernel<1, 32><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
                                                                  act, slope);
@@ -350,6 +692,31 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
     const int vecx = al16(x) && (ldx % 4 == 0);
     const int vecy = al16(y) && (ldy % 4 == 0);
     float* partial = chunks == 1 ? out : (float*)scratch;
+    const bool al8x = (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && ldx % 2 == 0;
+    const bool al8y = (reinterpret_cast<uintptr_t>(y) & 7u) == 0 && ldy % 2 == 0;
+    if (ws_gemm_variant == 2 && chunk * (ldx > ldy ? ldx : ldy) * 4 < (1ll << 31)) {
+        // per-wave tile (32 KT) x (32 NT); waves WK x WN over the output, the rest split the rows
+        const int kt = (k > 32 && al8x) ? 2 : 1, nt = (n > 32 && al8y) ? 2 : 1;
+        const int wk = k > 32 * kt ? 2 : 1;
+        const int wn = (n > 32 * nt && wk == 1) || (n > 32 * nt && k > 32 * kt) ? 2 : 1;
+#define WS_XTY2(KTV, NTV, WKV, WNV)                                                                                   \
+    gemm_xty2_kernel<KTV, NTV, WKV, WNV><<<dim3(chunks, (unsigned)ws_ceil_div(k, 32 * KTV * WKV),                     \
+                                                (unsigned)ws_ceil_div(n, 32 * NTV * WNV)), 256, 0, st>>>(             \
+        x, m, k, ldx, y, n, ldy, partial, chunk)
+#define WS_XTY2_W(KTV, NTV)                          \
+    do {                                             \
+        if (wk == 2 && wn == 2) WS_XTY2(KTV, NTV, 2, 2); \
+        else if (wk == 2) WS_XTY2(KTV, NTV, 2, 1);   \
+        else if (wn == 2) WS_XTY2(KTV, NTV, 1, 2);   \
+        else WS_XTY2(KTV, NTV, 1, 1);                \
+    } while (0)
+        if (kt == 2 && nt == 2) WS_XTY2_W(2, 2);
+        else if (kt == 2) WS_XTY2_W(2, 1);
+        else if (nt == 2) WS_XTY2_W(1, 2);
+        else WS_XTY2_W(1, 1);
+#undef WS_XTY2_W
+#undef WS_XTY2
+    } else {
 #define WS_XTY(NTV, KTV)                                                                                              \
     gemm_xty_kernel<NTV, KTV><<<dim3(chunks, (unsigned)ws_ceil_div(k, 32 * KTV), (unsigned)ws_ceil_div(n, 32 * NTV)), 256, 0, \
                                 st>>>(x, m, k, ldx, y, n, ldy, partial, chunk, vecx, vecy)
@@ -359,11 +726,12 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
         else if (k <= 64) WS_XTY(NTV, 2); \
         else WS_XTY(NTV, 4);             \
     } while (0)
-    if (n <= 32) WS_XTY_K(1);
-    else if (n <= 64) WS_XTY_K(2);
-    else WS_XTY_K(4);
+        if (n <= 32) WS_XTY_K(1);
+        else if (n <= 64) WS_XTY_K(2);
+        else WS_XTY_K(4);
 #undef WS_XTY_K
 #undef WS_XTY
+    }
     WS_LAUNCH_CHECK();
     if (chunks > 1) {
         const int64_t elems = (int64_t)k * n;
