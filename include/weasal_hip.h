@@ -148,6 +148,13 @@ int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b
 int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                         const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
                         float* y, int64_t ldy, void* stream);
+/* backward of that epilogue in one pass over [m,n]: dz = dy * (y > 0 ? 1 : slope)  (LeakyReLU backward from
+ * the OUTPUT y, models/blocks.py:500,564,709; y == NULL: no activation, dz untouched) and
+ * colsum[n] = sum over rows of dz (the gradient of the BatchNormBlock bias, blocks.py:465; NULL: skipped).
+ * Partial sums per row chunk in `scratch` (>= ws_act_bwd_colsum_scratch_bytes), added in a fixed order. */
+int64_t ws_act_bwd_colsum_scratch_bytes(int64_t m, int32_t n);
+int ws_act_bwd_colsum(const float* dy, int64_t m, int32_t n, int64_t lddy, const float* y, int64_t ldy, float slope,
+                      float* dz, int64_t lddz, float* colsum, void* scratch, void* stream);
 int64_t ws_gemm_xty_scratch_bytes(int64_t m, int32_t k, int32_t n);
 int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
                 float* out, void* scratch, void* stream);

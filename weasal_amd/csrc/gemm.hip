@@ -573,8 +573,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int64_t e = (int64_t)blockIdx.x * 32 + el;
     float s = 0.0f;
-    if (e < elems)
-        for (int c = grp; c < chunks; c += 8) s += partial[(int64_t)c * elems + e];
+    if (e < elems) {
+        int c = grp;
+        for (; c + 24 < chunks; c += 32) {                 // four loads in flight, added in order
+            const float v0 = partial[(int64_t)c * elems + e], v1 = partial[(int64_t)(c + 8) * elems + e];
+            const float v2 = partial[(int64_t)(c + 16) * elems + e], v3 = partial[(int64_t)(c + 24) * elems + e];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < chunks; c += 8) s += partial[(int64_t)c * elems + e];
+    }
     red[grp][el] = s;
     __syncthreads();
     if (grp == 0 && e < elems) {
@@ -583,6 +590,91 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         for (int g2 = 1; g2 < 8; ++g2) t += red[g2][el];
         out[e] = t;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dz = LeakyReLU'(y) * dy and the column sums of dz (the bias gradient of a BatchNormBlock,
+// models/blocks.py:465) in ONE pass over [m, n]: partial column sums per row chunk (threads = column
+// groups x row lanes, row lanes added through LDS in a fixed order), chunks added by
+// reduce_partials_kernel.  V = 4: float4 columns; V = 1: any n.
+// ---------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
+                                                              int64_t m, int n, int64_t lddy, int64_t ldy, float slope,
+                                                              float* __restrict__ dz, int64_t lddz,
+                                                              float* __restrict__ partial, int64_t chunk)
+{
+    __shared__ float red[256 * V];
+    const int t = threadIdx.x;
+    const int ncg = (n + V - 1) / V;                    // column groups
+    const int per = ncg < 256 ? ncg : 256;              // column groups per pass
+    const int R = 256 / per;                            // row lanes
+    const int rl = t / per, cgl = t % per;
+    const int64_t mbeg = (int64_t)blockIdx.x * chunk;
+    const int64_t mend = mbeg + chunk < m ? mbeg + chunk : m;
+    for (int cg0 = 0; cg0 < ncg; cg0 += per) {
+        const int cg = cg0 + cgl;
+        const int col = cg * V;
+        float s[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] = 0.0f;
+        if (rl < R && cg < ncg) {
+            typedef float vec_t __attribute__((ext_vector_type(V)));
+            const int64_t sdy = (int64_t)R * lddy, sy = (int64_t)R * ldy, sdz = (int64_t)R * lddz;
+            const float* pg = dy + (mbeg + rl) * lddy + col;
+            const float* pa = yact ? yact + (mbeg + rl) * ldy + col : nullptr;
+            float* pz = yact ? dz + (mbeg + rl) * lddz + col : nullptr;
+            auto one = [&](vec_t g, vec_t a, float* out) {
+                if (pa) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g[e] = a[e] > 0.0f ? g[e] : g[e] * slope;
+                    *reinterpret_cast<vec_t*>(out) = g;
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[e] += g[e];
+            };
+            int64_t r = mbeg + rl;
+            for (; r + 3 * R < mend; r += 4 * R) {        // four independent rows in flight per thread
+                vec_t g0 = *reinterpret_cast<const vec_t*>(pg), g1 = *reinterpret_cast<const vec_t*>(pg + sdy);
+                vec_t g2 = *reinterpret_cast<const vec_t*>(pg + 2 * sdy), g3 = *reinterpret_cast<const vec_t*>(pg + 3 * sdy);
+                vec_t a0 = g0, a1 = g1, a2 = g2, a3 = g3;
+                if (pa) {
+                    a0 = *reinterpret_cast<const vec_t*>(pa); a1 = *reinterpret_cast<const vec_t*>(pa + sy);
+                    a2 = *reinterpret_cast<const vec_t*>(pa + 2 * sy); a3 = *reinterpret_cast<const vec_t*>(pa + 3 * sy);
+                }
+                one(g0, a0, pz); one(g1, a1, pz + sdz); one(g2, a2, pz + 2 * sdz); one(g3, a3, pz + 3 * sdz);
+                pg += 4 * sdy;
+                if (pa) { pa += 4 * sy; pz += 4 * sdz; }
+            }
+            for (; r < mend; r += R) {
+                vec_t g0 = *reinterpret_cast<const vec_t*>(pg);
+                vec_t a0 = pa ? *reinterpret_cast<const vec_t*>(pa) : g0;
+                one(g0, a0, pz);
+                pg += sdy;
+                if (pa) { pa += sy; pz += sdz; }
+            }
+        }
+        if (partial) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[t * V + e] = s[e];
+            __syncthreads();
+            if (rl == 0 && cg < ncg) {
+                for (int q = 1; q < R; ++q)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) s[e] += red[(q * per + cgl) * V + e];
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (col + e < n) partial[(int64_t)blockIdx.x * n + col + e] = s[e];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+int64_t colsum_chunk(int64_t m)
+{
+    int64_t c = ws_ceil_div(m, 768);
+    return c < 128 ? 128 : c;                           // <= 768 chunks (three workgroups per CU) of >= 128 rows
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -661,6 +753,39 @@ int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const
                 x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr, act, slope);
     }
     WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+int64_t ws_act_bwd_colsum_scratch_bytes(int64_t m, int32_t n)
+{
+    return ws_ceil_div(m > 0 ? m : 1, colsum_chunk(m)) * (int64_t)n * (int64_t)sizeof(float);
+}
+
+int ws_act_bwd_colsum(const float* dy, int64_t m, int32_t n, int64_t lddy, const float* y, int64_t ldy, float slope,
+                      float* dz, int64_t lddz, float* colsum, void* scratch, void* stream)
+{
+    WS_REQUIRE(m >= 0 && n >= 1 && lddy >= n, "bad sizes m=%lld n=%d", (long long)m, n);
+    WS_REQUIRE(!y || (dz && ldy >= n && lddz >= n), "activation backward needs y and dz");
+    WS_REQUIRE(!colsum || scratch, "column sums need scratch");
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 0) {
+        if (colsum) WS_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)n, st));
+        return WS_OK;
+    }
+    WS_REQUIRE(dy && (y || colsum), "NULL argument");
+    const int64_t chunk = colsum_chunk(m);
+    const int chunks = (int)ws_ceil_div(m, chunk);
+    float* partial = colsum ? (chunks == 1 ? colsum : (float*)scratch) : nullptr;
+    const bool vec = n % 4 == 0 && al16(dy) && lddy % 4 == 0 && (!y || (al16(y) && ldy % 4 == 0 && al16(dz) && lddz % 4 == 0));
+    if (vec)
+        act_bwd_colsum_kernel<4><<<chunks, 256, 0, st>>>(dy, y, m, n, lddy, ldy, slope, dz, lddz, partial, chunk);
+    else
+        act_bwd_colsum_kernel<1><<<chunks, 256, 0, st>>>(dy, y, m, n, lddy, ldy, slope, dz, lddz, partial, chunk);
+    WS_LAUNCH_CHECK();
+    if (colsum && chunks > 1) {
+        reduce_partials_kernel<<<(unsigned)ws_ceil_div(n, 32), 256, 0, st>>>(partial, n, chunks, colsum);
+        WS_LAUNCH_CHECK();
+    }
     return WS_OK;
 }
 

@@ -255,6 +255,24 @@ def _rowmajor(t):
     return t if (t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
 
 
+def _act_bwd_colsum(dy, y, slope, want_colsum):
+    """(dz, column sums of dz or None): LeakyReLU backward from the output y (None: identity) and the
+    bias gradient in one pass (ws_act_bwd_colsum)"""
+    if y is None and not want_colsum:
+        return dy, None
+    lib = _lib.lib()
+    m, n = dy.shape
+    dz = torch.empty((m, n), dtype=torch.float32, device=dy.device) if y is not None else dy
+    colsum = scratch = None
+    if want_colsum:
+        colsum = torch.empty((n,), dtype=torch.float32, device=dy.device)
+        scratch = torch.empty(max(lib.ws_act_bwd_colsum_scratch_bytes(m, n), 16), dtype=torch.uint8, device=dy.device)
+    check(lib.ws_act_bwd_colsum(ptr(dy), m, n, dy.stride(0), ptr(y), y.stride(0) if y is not None else 0,
+                                0.0 if slope is None else float(slope), ptr(dz) if y is not None else None, n,
+                                ptr(colsum), ptr(scratch), current_stream()))
+    return dz, colsum
+
+
 class _MatmulEpilogue(torch.autograd.Function):
     """y = act(x @ b + bias + residual), act = LeakyReLU(slope) or identity; the activation
     backward uses the output (sign(y) == sign(pre-activation) for slope > 0)."""
@@ -280,9 +298,10 @@ class _MatmulEpilogue(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.lib()
         x, b, y = ctx.saved_tensors
-        dz = dy if ctx.slope is None else torch.ops.aten.leaky_relu_backward(dy, y, ctx.slope, True)
-        dz = _rowmajor(dz)
-        dx = db = dbias = dres = None
+        dy = _rowmajor(dy)
+        want_bias = ctx.has[0] and ctx.needs_input_grad[2]
+        dz, dbias = _act_bwd_colsum(dy, y if ctx.slope is not None else None, ctx.slope, want_bias)
+        dx = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = _gemm_xb(dz, b.t().contiguous())
         if ctx.needs_input_grad[1]:
@@ -292,8 +311,6 @@ class _MatmulEpilogue(torch.autograd.Function):
             scratch = torch.empty(max(lib.ws_gemm_xty_scratch_bytes(m, k, n), 16), dtype=torch.uint8, device=x.device)
             check(lib.ws_gemm_xty(ptr(x), m, k, x.stride(0), ptr(dz), n, dz.stride(0), ptr(db), ptr(scratch),
                                   current_stream()))
-        if ctx.has[0] and ctx.needs_input_grad[2]:
-            dbias = dz.sum(0)
         if ctx.has[1] and ctx.needs_input_grad[3]:
             dres = dz
         return dx, db, dbias, dres, None
