@@ -239,7 +239,7 @@ def main():
                     traffic = json.load(open(tpath)).get("kpconv_gather_fwd_enc1_bytes_per_launch")
                 except Exception:
                     traffic = None
-            res["roofline"] = {"bound": "hbm", "kernel": "kpconv_gather_fwd_kernel<15,32> (enc1: N=%d, H=%d, Ci=%d)" % (nq, h, ci),
+            res["roofline"] = {"bound": "hbm", "kernel": "kpconv_gather_fwd_kernel<15,8,0,false,true> (enc1: N=%d, H=%d, Ci=%d)" % (nq, h, ci),
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": ms_k, "launches_timed": count}

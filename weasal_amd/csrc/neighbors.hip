@@ -278,8 +278,7 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
 //    their first 64 candidates fetched together, so nine independent gathers are in flight instead
 //    of nine dependent round trips;
 //  * hits are compacted through the wave's LDS slab, then each lane takes two keys (i and i+64) and
-//    the 128-key bitonic network runs in registers with cross-lane shuffles -- no LDS round trip
-//    and no barrier per stage (21 stages when the row has <= 64 hits, 28 otherwise).
+//    finds their sorted positions by counting the smaller keys (LDS broadcast reads).
 template <typename OutT>
 __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict__ queries, int64_t nq,
                                                           const CloudGrid* __restrict__ grids, int nb,
@@ -350,40 +349,28 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
         cnt = min(cnt, CAP);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        unsigned long long a = lane < cnt ? slab[lane] : ~0ull;
-        unsigned long long bkey = lane + 64 < cnt ? slab[lane + 64] : ~0ull;
+        // rank by counting: the keys are distinct (the index is part of the key), so the number of smaller
+        // keys IS the sorted position.  Every lane compares its (up to) two keys with key i, read as an LDS
+        // broadcast -- independent iterations, no cross-lane shuffle and no dependent latency chain (the
+        // 128-key bitonic network this replaces was 28 serially dependent shuffle stages).
+        const unsigned long long a = lane < cnt ? slab[lane] : ~0ull;
+        const unsigned long long bkey = lane + 64 < cnt ? slab[lane + 64] : ~0ull;
+        int ra = 0, rb = 0;
         if (cnt <= 64) {
-#pragma unroll
-            for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    const unsigned long long o = __shfl_xor(a, j, 64);
-                    const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-                    a = keep_min ? (o < a ? o : a) : (o > a ? o : a);
-                }
-            }
+#pragma unroll 8
+            for (int i = 0; i < cnt; ++i) ra += slab[i] < a ? 1 : 0;
         } else {
-#pragma unroll
-            for (int k = 2; k <= 128; k <<= 1) {
-#pragma unroll
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    if (j == 64) {                       // partner is the lane's own second key; direction up
-                        const unsigned long long lo = a < bkey ? a : bkey, hi = a < bkey ? bkey : a;
-                        a = lo; bkey = hi;
-                    } else {
-                        const unsigned long long oa = __shfl_xor(a, j, 64), ob = __shfl_xor(bkey, j, 64);
-                        const bool lower = (lane & j) == 0;
-                        const bool up_a = k >= 128 ? true : ((lane & k) == 0);
-                        const bool up_b = k >= 128 ? true : (k == 64 ? false : ((lane & k) == 0));
-                        a = (lower == up_a) ? (oa < a ? oa : a) : (oa > a ? oa : a);
-                        bkey = (lower == up_b) ? (ob < bkey ? ob : bkey) : (ob > bkey ? ob : bkey);
-                    }
-                }
+#pragma unroll 8
+            for (int i = 0; i < cnt; ++i) {
+                const unsigned long long kk = slab[i];
+                ra += kk < a ? 1 : 0;
+                rb += kk < bkey ? 1 : 0;
             }
         }
-        if (lane < width) out[q * width + lane] = lane < cnt ? (OutT)(unsigned)(a & 0xffffffffull) : (OutT)ns;
-        if (lane + 64 < width) out[q * width + lane + 64] = lane + 64 < cnt ? (OutT)(unsigned)(bkey & 0xffffffffull) : (OutT)ns;
-        for (int j = lane + 128; j < width; j += 64) out[q * width + j] = (OutT)ns;
+        OutT* orow = out + q * width;
+        if (lane < cnt && ra < width) orow[ra] = (OutT)(unsigned)(a & 0xffffffffull);
+        if (lane + 64 < cnt && rb < width) orow[rb] = (OutT)(unsigned)(bkey & 0xffffffffull);
+        for (int j = cnt + lane; j < width; j += 64) orow[j] = (OutT)ns;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
