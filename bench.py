@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
+    ap.add_argument("--contrast", type=int, default=0,
+                    help="1: add KPFCNN.contrast_loss to the step (trainer_PseudoLabel.py:204-208; SURVEY 8f-2, "
+                         "outside the north_star step, so off by default)")
     ap.add_argument("--blas", default="", help="torch.backends.cuda.preferred_blas_library (A/B only)")
     ap.add_argument("--prefetch", type=int, default=1,
                     help="1: build the pyramid of the next batches on a second HIP stream / host thread while the "
@@ -173,7 +176,7 @@ def main():
         else:
             pts, feats, labels, lens = inputs[i % nd]
             batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
-        loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync)
+        loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync, epoch=0 if args.contrast else None)
         return loss
 
     # Runtime warm-up, untimed and before the W warm-up steps: the HIP runtime grows its launch

@@ -4,8 +4,10 @@
 keep the reference's names, wiring and state_dict keys (models/architectures.py:192-403), so
 ``utils/trainer_PseudoLabel.py`` drives this class unchanged; every KPConv / pooling operator
 underneath is a HIP kernel (weasal_amd/blocks.py).  ``p2p_fitting_regularizer`` follows
-architectures.py:24-57.  Not provided here: ``contrast_loss`` (architectures.py:405-504, needs
-torch_scatter) and the weak-label ``KPFCNN_mprm`` (rank 3).
+architectures.py:24-57.  ``contrast_loss`` (architectures.py:405-504) is restated without torch_scatter and
+without ``.cuda()`` calls (**parity unpinned**: torch_scatter is absent, so the
+reference function has never run here -- it is checked against oracle/contrast_ref.py only).  Not provided: the
+weak-label ``KPFCNN_mprm`` (rank 3).
 """
 import numpy as np
 import torch
@@ -166,6 +168,73 @@ class KPFCNN(nn.Module):
         else:
             raise ValueError('Unknown fitting mode: ' + self.deform_fitting_mode)
         return self.output_loss + self.reg_loss
+
+    def contrast_loss(self, outputs, labels, config, threshold=0.2, slice_draw=None):
+        """Supervised contrastive loss of the pseudo-label trainer (architectures.py:405-504,
+        trainer_PseudoLabel.py:204-208): every point is compared with a slice of 1000 randomly drawn
+        valid points; positives share the (pseudo) label.  Same arithmetic on the device of `outputs`;
+        the `[N, slc_con]` slice mask is the comparison `arange(N)[:, None] != slc_idx[None, :]` (the
+        reference builds it with where + scatter), and `torch_scatter.scatter(reduce="mean")` over the
+        pseudo labels is an index_add of sums and counts (classes without points drop out with the
+        reference's `> 0` filter).  `slice_draw`: optional LongTensor replacing the `torch.randint`
+        draw (tests); `threshold` is overwritten by `config.contrast_thd / 100` as in the reference."""
+        temperature = 0.1
+        base_temperature = 1
+        slc_con = 1000
+        dev = outputs.device
+        N = outputs.shape[0]
+        eps = 1e-8
+        threshold = config.contrast_thd / 100
+        self.pts_loss = 0
+        self.pts_loss_self = 0
+
+        prob = torch.softmax(outputs, 1)
+        pseudo_logits = prob.max(1)[0]
+        label_id = labels < 10                                   # > 10 = unlabeled (:430-433)
+        certain_label = (pseudo_logits > threshold) | label_id
+        pseudo_lbs = torch.argmax(prob, dim=1)
+        pseudo_lbs = torch.where(label_id, labels.to(pseudo_lbs.dtype), pseudo_lbs)
+        all_valid_idx = torch.where(certain_label)[0]
+        num_valid = all_valid_idx.shape[0]
+        if num_valid < 1:
+            print('Skipped loss calculations because there are no valid points in batch')
+            return torch.zeros((), dtype=torch.float32, device=dev)
+        n_draw = slc_con if num_valid >= slc_con else slc_con - num_valid
+        if slice_draw is None:
+            slice_draw = torch.randint(0, num_valid, (n_draw,))
+        slice_draw = slice_draw.to(dev)
+        if num_valid >= slc_con:
+            slc_idx_idx = slice_draw
+        else:
+            slc_idx_idx = torch.cat((torch.arange(num_valid, device=dev), slice_draw), dim=0)
+        slc_idx = all_valid_idx[slc_idx_idx]
+
+        # the three [N, slc_con] masks (:455-476) as one boolean matrix each
+        use = (torch.arange(N, device=dev)[:, None] != slc_idx[None, :]) & \
+              (certain_label[slc_idx][None, :] == certain_label[:, None])           # mask_slice * mask_certain
+        pos = use & (pseudo_lbs[slc_idx][None, :] == pseudo_lbs[:, None])           # ... * mask_positive
+
+        outputs = nn.functional.normalize(outputs, dim=1)
+        mul = torch.matmul(outputs, outputs[slc_idx].T) / temperature
+        logits = mul - torch.max(mul, dim=1, keepdim=True)[0].detach()
+        usef = use.to(logits.dtype)
+        exp_sum = (torch.exp(logits) * usef).sum(1, keepdim=True)
+        log_prob = (logits - torch.log(exp_sum + eps)) * usef
+        posf = pos.to(logits.dtype)
+        mean_log_prob_pos = (posf * log_prob).sum(1) / (posf.sum(1) + 1e-12)
+        pts_loss = -(temperature / base_temperature) * mean_log_prob_pos
+        cal_slc = pts_loss > 0
+        pts_loss = pts_loss[cal_slc]
+        cls = pseudo_lbs[cal_slc]
+        if pts_loss.numel() == 0:                                 # scatter of nothing, mean of nothing (:499-504)
+            self.pts_loss = pts_loss
+            return pts_loss.mean()
+        n_cls = int(cls.max()) + 1
+        sums = torch.zeros(n_cls, dtype=pts_loss.dtype, device=dev).index_add(0, cls, pts_loss)
+        cnts = torch.zeros(n_cls, dtype=pts_loss.dtype, device=dev).index_add(0, cls, torch.ones_like(pts_loss))
+        per_class = sums / cnts.clamp(min=1)
+        self.pts_loss = per_class[per_class > 0]
+        return self.pts_loss.mean()
 
     def accuracy(self, outputs, labels):
         target = self._targets(labels)

@@ -101,6 +101,8 @@ _PL_ARCH = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided'
 class DALESPLConfig(Config):
     """values of train_DALES_PseudoLabel.py:44-201 that reach the hot path"""
     dataset = 'DALESPL'
+    contrast_start = 0        # train_DALES_PseudoLabel.py:181-182
+    contrast_thd = 10
     input_threads = 10
     architecture = list(_PL_ARCH)
     num_kernel_points = 15

@@ -21,12 +21,15 @@ def make_optimizer(net, config):
                            weight_decay=config.weight_decay)
 
 
-def train_step(net, optimizer, batch, config, grad_sync=None):
+def train_step(net, optimizer, batch, config, grad_sync=None, epoch=None):
     """-> (loss tensor, logits).  grad_sync: optional callable(net) run between backward and clip
-    (weasal_amd.dp.GradSync: one flat RCCL all-reduce)."""
+    (weasal_amd.dp.GradSync: one flat RCCL all-reduce).  epoch: when given, the supervised contrastive
+    loss joins from `config.contrast_start` on (trainer_PseudoLabel.py:204-208)."""
     optimizer.zero_grad(set_to_none=False)
     outputs = net(batch, config)
     loss = net.loss(outputs, batch.labels)
+    if epoch is not None and epoch >= getattr(config, 'contrast_start', 1 << 30):
+        loss = loss + net.contrast_loss(outputs, batch.labels, config)
     loss.backward()
     if grad_sync is not None:
         grad_sync(net)
