@@ -253,6 +253,25 @@ int ws_rotate_clouds(const float* points, int64_t n, const int32_t* lens /*devic
 int ws_rotate_clouds_host(const float* points, int64_t n, const int32_t* h_lens, int32_t nb,
                           const float* h_rot, int32_t transpose, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Supervised contrastive loss of the pseudo-label trainer, the [N, slc_con] part of
+ * KPFCNN.contrast_loss (models/architectures.py:455-497), fused: per point i
+ *   loss[i] = -T * mean over the positive slice columns of log-softmax(<on_i, xs_j>/T over the usable columns)
+ * with usable = (slc_idx[j] != i) and certain[slc_idx[j]] == certain[i], positive = usable and
+ * lbl[slc_idx[j]] == lbl[i].  on [n,c] = L2-normalised logits (:475), xs [s,c] = on[slc_idx] (:476),
+ * certain [n] uint8 (:433-435), lbl [n] int64 pseudo labels (:438-439).  rowmax / den / npos [n] are saved
+ * for the backward, which returns d loss / d on (d_on [n,c], the slice rows' own contribution excluded) and
+ * d loss / d xs (d_xs [s,c]; per-chunk partials in `scratch`, added in a fixed order).  c <= 16, s <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+int ws_contrast_rows_fwd(const float* on, int64_t n, int32_t c, const float* xs, int32_t s, const int64_t* slc_idx,
+                         const uint8_t* certain, const int64_t* lbl, float temperature, float eps, float* loss,
+                         float* rowmax, float* den, float* npos, void* stream);
+int64_t ws_contrast_rows_bwd_scratch_bytes(int64_t n, int32_t c, int32_t s);
+int ws_contrast_rows_bwd(const float* on, int64_t n, int32_t c, const float* xs, int32_t s, const int64_t* slc_idx,
+                         const uint8_t* certain, const int64_t* lbl, float temperature, const float* rowmax,
+                         const float* den, const float* npos, const float* g, float* d_on, float* d_xs, void* scratch,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

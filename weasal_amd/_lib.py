@@ -37,6 +37,10 @@ SIGNATURES = {
     "ws_gemm_xb_epilogue": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
     "ws_act_bwd_colsum_scratch_bytes": (_i64, [_i64, _i32]),
     "ws_act_bwd_colsum": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, C.c_float, _vp, _i64, _vp, _vp, _vp]),
+    "ws_contrast_rows_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "ws_contrast_rows_bwd_scratch_bytes": (_i64, [_i64, _i32, _i32]),
+    "ws_contrast_rows_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp]),
     "ws_gemm_xty_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "ws_gemm_xty": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp]),
     "ws_neighbors_ws_create": (C.c_int, [C.POINTER(_vp)]),

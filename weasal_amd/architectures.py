@@ -172,11 +172,11 @@ class KPFCNN(nn.Module):
     def contrast_loss(self, outputs, labels, config, threshold=0.2, slice_draw=None):
         """Supervised contrastive loss of the pseudo-label trainer (architectures.py:405-504,
         trainer_PseudoLabel.py:204-208): every point is compared with a slice of 1000 randomly drawn
-        valid points; positives share the (pseudo) label.  Same arithmetic on the device of `outputs`;
-        the `[N, slc_con]` slice mask is the comparison `arange(N)[:, None] != slc_idx[None, :]` (the
-        reference builds it with where + scatter), and `torch_scatter.scatter(reduce="mean")` over the
-        pseudo labels is an index_add of sums and counts (classes without points drop out with the
-        reference's `> 0` filter).  `slice_draw`: optional LongTensor replacing the `torch.randint`
+        valid points; positives share the (pseudo) label.  The `[N, slc_con]` part (three masks, similarities,
+        masked log-softmax, mean over positives; six 1.6 GB matrices in the reference at N = 400 000) is the
+        fused HIP operator `ops.contrast_rows`; `torch_scatter.scatter(reduce="mean")` over the pseudo labels
+        is an index_add of sums and counts (classes without points drop out with the reference's `> 0`
+        filter).  `slice_draw`: optional LongTensor replacing the `torch.randint`
         draw (tests); `threshold` is overwritten by `config.contrast_thd / 100` as in the reference."""
         temperature = 0.1
         base_temperature = 1
@@ -209,32 +209,23 @@ class KPFCNN(nn.Module):
             slc_idx_idx = torch.cat((torch.arange(num_valid, device=dev), slice_draw), dim=0)
         slc_idx = all_valid_idx[slc_idx_idx]
 
-        # the three [N, slc_con] masks (:455-476) as one boolean matrix each
-        use = (torch.arange(N, device=dev)[:, None] != slc_idx[None, :]) & \
-              (certain_label[slc_idx][None, :] == certain_label[:, None])           # mask_slice * mask_certain
-        pos = use & (pseudo_lbs[slc_idx][None, :] == pseudo_lbs[:, None])           # ... * mask_positive
-
+        # [N, slc_con] part (:455-497): masks, temperature-scaled similarities, masked log-softmax and the mean
+        # over the positives -- one fused HIP kernel per direction, nothing of size [N, slc_con] is stored
         outputs = nn.functional.normalize(outputs, dim=1)
-        mul = torch.matmul(outputs, outputs[slc_idx].T) / temperature
-        logits = mul - torch.max(mul, dim=1, keepdim=True)[0].detach()
-        usef = use.to(logits.dtype)
-        exp_sum = (torch.exp(logits) * usef).sum(1, keepdim=True)
-        log_prob = (logits - torch.log(exp_sum + eps)) * usef
-        posf = pos.to(logits.dtype)
-        mean_log_prob_pos = (posf * log_prob).sum(1) / (posf.sum(1) + 1e-12)
-        pts_loss = -(temperature / base_temperature) * mean_log_prob_pos
-        cal_slc = pts_loss > 0
-        pts_loss = pts_loss[cal_slc]
-        cls = pseudo_lbs[cal_slc]
-        if pts_loss.numel() == 0:                                 # scatter of nothing, mean of nothing (:499-504)
-            self.pts_loss = pts_loss
-            return pts_loss.mean()
-        n_cls = int(cls.max()) + 1
-        sums = torch.zeros(n_cls, dtype=pts_loss.dtype, device=dev).index_add(0, cls, pts_loss)
-        cnts = torch.zeros(n_cls, dtype=pts_loss.dtype, device=dev).index_add(0, cls, torch.ones_like(pts_loss))
+        pts_loss = ops.contrast_rows(outputs, outputs[slc_idx], slc_idx, certain_label, pseudo_lbs, temperature, eps)
+        if base_temperature != 1:
+            pts_loss = pts_loss / base_temperature
+        # :498-504 without host synchronisation: points with loss <= 0 are dropped, the rest averaged per
+        # pseudo label (scatter-mean), classes whose mean is not > 0 (or empty) dropped, then the mean.
+        # Pseudo labels are argmax indices or given labels < 10, so max(C, 10) bins cover them.
+        keep = (pts_loss > 0).to(pts_loss.dtype)
+        n_cls = max(int(outputs.shape[1]), 10)
+        sums = torch.zeros(n_cls, dtype=pts_loss.dtype, device=dev).index_add(0, pseudo_lbs, pts_loss * keep)
+        cnts = torch.zeros(n_cls, dtype=pts_loss.dtype, device=dev).index_add(0, pseudo_lbs, keep)
         per_class = sums / cnts.clamp(min=1)
-        self.pts_loss = per_class[per_class > 0]
-        return self.pts_loss.mean()
+        sel = (per_class > 0).to(pts_loss.dtype)
+        self.pts_loss = per_class
+        return (per_class * sel).sum() / sel.sum()
 
     def accuracy(self, outputs, labels):
         target = self._targets(labels)

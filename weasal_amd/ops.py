@@ -650,3 +650,50 @@ def rotate_clouds(points, lens_dev, rot, transpose=False):
     check(lib.ws_rotate_clouds(ptr(p), p.shape[0], ptr(lens_dev), lens_dev.shape[0], ptr(rot.contiguous()),
                                1 if transpose else 0, ptr(out), current_stream()))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# supervised contrastive loss, the [N, slc_con] part (KPFCNN.contrast_loss, architectures.py:455-497)
+# ------------------------------------------------------------------------------------------------
+class _ContrastRows(torch.autograd.Function):
+    """loss[i] of every point against the slice rows; gradients to the normalised logits `on` (as point
+    rows) and to the slice rows `xs` (= on[slc_idx], indexed by the caller so autograd adds them back)."""
+
+    @staticmethod
+    def forward(ctx, on, xs, slc_idx, certain, lbl, temperature, eps):
+        lib = _lib.lib()
+        on, xs = on.contiguous(), xs.contiguous()
+        n, c = on.shape
+        s = xs.shape[0]
+        slc_idx = slc_idx.to(torch.int64).contiguous()
+        certain = certain.to(torch.uint8).contiguous()
+        lbl = lbl.to(torch.int64).contiguous()
+        loss, rowmax, den, npos = (torch.empty((n,), dtype=torch.float32, device=on.device) for _ in range(4))
+        check(lib.ws_contrast_rows_fwd(ptr(on), n, c, ptr(xs), s, ptr(slc_idx), ptr(certain), ptr(lbl),
+                                       float(temperature), float(eps), ptr(loss), ptr(rowmax), ptr(den), ptr(npos),
+                                       current_stream()))
+        ctx.save_for_backward(on, xs, slc_idx, certain, lbl, rowmax, den, npos)
+        ctx.temperature = float(temperature)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.lib()
+        on, xs, slc_idx, certain, lbl, rowmax, den, npos = ctx.saved_tensors
+        n, c = on.shape
+        s = xs.shape[0]
+        g = g.contiguous().float()
+        d_on = torch.empty_like(on)
+        d_xs = torch.empty_like(xs)
+        scratch = torch.empty(max(lib.ws_contrast_rows_bwd_scratch_bytes(n, c, s), 16), dtype=torch.uint8, device=on.device)
+        check(lib.ws_contrast_rows_bwd(ptr(on), n, c, ptr(xs), s, ptr(slc_idx), ptr(certain), ptr(lbl), ctx.temperature,
+                                       ptr(rowmax), ptr(den), ptr(npos), ptr(g), ptr(d_on), ptr(d_xs), ptr(scratch),
+                                       current_stream()))
+        return d_on, d_xs, None, None, None, None, None
+
+
+def contrast_rows(on, xs, slc_idx, certain, lbl, temperature, eps):
+    """per-point supervised contrastive loss [N] (ws_contrast_rows_fwd / _bwd); on [N,C] normalised logits,
+    xs [S,C] = on[slc_idx], certain [N] bool, lbl [N] pseudo labels"""
+    _need_cuda(on, xs)
+    return _ContrastRows.apply(on, xs, slc_idx, certain, lbl, temperature, eps)
