@@ -95,7 +95,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // MODE 1 keeps every influence / aggregation / deformable combination behind runtime switches.
 // ---------------------------------------------------------------------------------------------
 constexpr int POOL = 256;                 // real entries per wave (8 B each), >= 16 * 15
-constexpr int POOL_ALLOC = POOL + 8 + 64;  // + read-past slack of the flush + one dummy slot per lane
+constexpr int POOL_ALLOC = POOL + 8 + 128; // + read-past slack of the flush + two dummy slots per lane
 
 __device__ __forceinline__ int lane_rank(unsigned long long m)
 {
@@ -198,6 +198,38 @@ __device__ __forceinline__ void kp_list(float nx, float ny, float nz, bool live,
                 emit(k, w);
             }
         }
+    }
+    segs[K] = total;
+}
+
+// List phase for TWO 64-lane column chunks at once (rigid / linear / sum only): lane = columns c and
+// c + 64.  Rows of 65..128 neighbours (the calibrated limits of the deeper pyramid levels sit at
+// 70-75) then need ONE pool and ONE flush instead of a second, nearly empty chunk that re-reads and
+// re-writes all K rows of wf[q].
+template <int K, typename KPF>
+__device__ __forceinline__ void kp_list2(float ax, float ay, float az, bool alive, unsigned arow, float bx, float by, float bz,
+                                         bool blive, unsigned brow, KPF kp, float inv_extent, uint2* pool, int* segs, int lane,
+                                         int& total, int& maxlen)
+{
+    const unsigned dummy_a = POOL + 8 + lane, dummy_b = POOL + 8 + 64 + lane;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float kx = kp(k, 0), ky = kp(k, 1), kz = kp(k, 2);
+        const float dxa = ax - kx, dya = ay - ky, dza = az - kz;
+        const float dxb = bx - kx, dyb = by - ky, dzb = bz - kz;
+        float wa = fmaxf(1.0f - __builtin_amdgcn_sqrtf((dxa * dxa + dya * dya) + dza * dza) * inv_extent, 0.0f);
+        float wb = fmaxf(1.0f - __builtin_amdgcn_sqrtf((dxb * dxb + dyb * dyb) + dzb * dzb) * inv_extent, 0.0f);
+        wa = alive ? wa : 0.0f;
+        wb = blive ? wb : 0.0f;
+        const unsigned long long ma = __ballot(wa != 0.0f), mb = __ballot(wb != 0.0f);
+        const int ca = __builtin_popcountll(ma), cb = __builtin_popcountll(mb);
+        const unsigned pa = (unsigned)(total + lane_rank(ma)), pb = (unsigned)(total + ca + lane_rank(mb));
+        const bool oka = (wa != 0.0f) && pa < (unsigned)POOL, okb = (wb != 0.0f) && pb < (unsigned)POOL;
+        pool[oka ? pa : dummy_a] = make_uint2(arow, __float_as_uint(wa));
+        pool[okb ? pb : dummy_b] = make_uint2(brow, __float_as_uint(wb));
+        segs[k] = total;
+        total += ca + cb;
+        maxlen = max(maxlen, ca + cb);
     }
     segs[K] = total;
 }
@@ -339,6 +371,25 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
             const bool real = incol && idx >= 0;
             const float nx = px - qx, ny = py - qy, nz = pz - qz;
             const unsigned row = (unsigned)(real ? idx : 0);
+            int total = 0, maxlen = 0;
+            if (MODE == 0 && h - h0 > 64) {
+                // 65..128 columns left: both chunks into one pool, one flush
+                const int colb = col + 64;
+                int idxb = -1;
+                if (colb < h) { const int64_t v = inds[q * h + colb]; idxb = (v >= 0 && v < ns) ? (int)v : -1; }
+                float bx, by, bz;
+                load_pt(idxb, bx, by, bz);
+                const bool realb = idxb >= 0;
+                kp_list2<K>(nx, ny, nz, real, row, bx - qx, by - qy, bz - qz, realb, (unsigned)(realb ? idxb : 0), kp, inv_extent,
+                            pool, segs, lane, total, maxlen);
+                if (total <= POOL) {
+                    flush(q, accumulate, maxlen);
+                    accumulate = true;
+                    h0 += 64;
+                    continue;
+                }
+                total = 0; maxlen = 0;      // does not fit: fall through, one chunk at a time
+            }
             auto minf = [&](int k, float d) {
                 if (DEF && min_d2) {
                     float m = incol ? d : 3.4e38f;
@@ -347,7 +398,6 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
                     if (lane == 0) min_d2[q * K + k] = h0 == 0 ? m : fminf(min_d2[q * K + k], m);
                 }
             };
-            int total = 0, maxlen = 0;
             kp_list<K, MODE>(nx, ny, nz, real, kp, g, inv_extent, row, 0u, nullptr, pool, segs, lane, total, maxlen, minf);
             if (total <= POOL) {
                 flush(q, accumulate, maxlen);
