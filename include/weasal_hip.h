@@ -148,6 +148,13 @@ int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b
 int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                         const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
                         float* y, int64_t ldy, void* stream);
+/* the same with split-K for short, deep products (m below ~32 k rows, k >= 512: the bottom of the pyramid):
+ * up to 16 workgroup layers contract disjoint k ranges into `scratch` (>= ws_gemm_xb_scratch_bytes, may be
+ * 0 = never split) and a second kernel adds them in a fixed order and applies the epilogue. */
+int64_t ws_gemm_xb_scratch_bytes(int64_t m, int32_t k, int32_t n);
+int ws_gemm_xb_epilogue_splitk(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+                               const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
+                               float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream);
 /* backward of that epilogue in one pass over [m,n]: dz = dy * (y > 0 ? 1 : slope)  (LeakyReLU backward from
  * the OUTPUT y, models/blocks.py:500,564,709; y == NULL: no activation, dz untouched) and
  * colsum[n] = sum over rows of dz (the gradient of the BatchNormBlock bias, blocks.py:465; NULL: skipped).

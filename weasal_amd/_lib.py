@@ -41,6 +41,9 @@ SIGNATURES = {
     "ws_contrast_rows_bwd_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "ws_contrast_rows_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp]),
+    "ws_gemm_xb_scratch_bytes": (_i64, [_i64, _i32, _i32]),
+    "ws_gemm_xb_epilogue_splitk": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _vp, _i64, _i32, C.c_float, _vp, _i64,
+                                             _vp, _i64, _vp]),
     "ws_gemm_xty_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "ws_gemm_xty": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp]),
     "ws_neighbors_ws_create": (C.c_int, [C.POINTER(_vp)]),

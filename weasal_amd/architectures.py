@@ -152,10 +152,19 @@ class KPFCNN(nn.Module):
 
     def _targets(self, labels):
         """labels -> class index in [0, C) or -1 for ignored labels (architectures.py:362-365)"""
-        target = -torch.ones_like(labels)
-        for i, c in enumerate(self.valid_labels):
-            target[labels == c] = i
-        return target
+        # one table gather instead of the reference's loop of masked assignments (same mapping)
+        lut = getattr(self, "_target_lut", None)
+        if lut is None or lut.device != labels.device:
+            vmax = int(max(int(np.max(self.valid_labels)) if len(self.valid_labels) else 0, 0))
+            lut = -torch.ones(vmax + 2, dtype=torch.int64)
+            for i, c in enumerate(self.valid_labels):
+                if 0 <= int(c) <= vmax:
+                    lut[int(c)] = i
+            lut = lut.to(labels.device)
+            self._target_lut = lut
+        # labels outside the table (ignored / unlabeled values) map to -1 through the last, spare entry
+        idx = torch.where((labels >= 0) & (labels < lut.shape[0] - 1), labels, torch.full_like(labels, lut.shape[0] - 1))
+        return lut[idx]
 
     def loss(self, outputs, labels):
         """cross entropy over [1, C, N] with ignore_index -1, plus the deformable regulariser"""

@@ -46,19 +46,13 @@ __global__ __launch_bounds__(256) void tr_sort_lists(const int32_t* __restrict__
         const int n = end - beg;
         if (n <= 1) continue;
         if (n <= 64) {
-            // in-register bitonic over the 64 lanes
-            int v = lane < n ? pairs[beg + lane] : 0x7fffffff;
-#pragma unroll
-            for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    const int o = __shfl_xor(v, j, 64);
-                    const bool up = (lane & k) == 0;
-                    const bool lower = (lane & j) == 0;
-                    v = (lower == up) ? min(v, o) : max(v, o);
-                }
-            }
-            if (lane < n) pairs[beg + lane] = v;
+            // rank by counting: pair ids are distinct, so the number of smaller ids is the sorted position.
+            // Key i is broadcast with v_readlane (uniform loop index): independent compare + add per
+            // iteration instead of 21 dependent shuffle stages of a bitonic network.
+            const int v = lane < n ? pairs[beg + lane] : 0x7fffffff;
+            int r = 0;
+            for (int i = 0; i < n; ++i) r += __builtin_amdgcn_readlane(v, i) < v ? 1 : 0;
+            if (lane < n) pairs[beg + r] = v;
         } else if (n <= SORT_CAP) {
             int m = 64;
             while (m < n) m <<= 1;

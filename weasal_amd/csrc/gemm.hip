@@ -205,8 +205,10 @@ template <int NT, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_xb2_kernel(
     const float* __restrict__ x, int64_t m, int k, int64_t ldx, const float* __restrict__ b, int n, int ldb,
     float* __restrict__ y, int64_t ldy, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldr,
-    int act, float slope)
+    int act, float slope, int csplit, float* __restrict__ partial)
 {
+    // split-K (gridDim.z > 1; few rows, deep k): workgroup z contracts chunks [z*csplit, (z+1)*csplit) and
+    // writes its raw sums to partial[z][m][n]; splitk_epilogue_kernel adds them in a fixed order
     constexpr int WM = 4 / WN;                            // wave grid WM x WN: rows x column groups
     constexpr int CT = NT * WN;                           // 32-column tiles per workgroup
     constexpr int BN = 32 * CT;
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     const int idx = lane & 31, h = lane >> 5;
     const int64_t row = (int64_t)blockIdx.x * (32 * WM) + wm * 32 + idx;
     const int n0 = blockIdx.y * BN;
-    const int nchunks = k / KC;
+    const int cbeg = blockIdx.z * csplit;
+    const int cend = (cbeg + csplit) * KC < k ? cbeg + csplit : k / KC;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -274,25 +277,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
         }
     };
 
-    const int last = nchunks - 1;
-    load_w(0);
-    load_x(0);
+    const int last = cend - 1;
+    load_w(cbeg);
+    load_x(cbeg);
     {   // chunk 1 of W goes out before anything waits on chunk 0
         float4 w0[CT];
 #pragma unroll
         for (int i = 0; i < CT; ++i) w0[i] = wv[i];
-        load_w(last < 1 ? last : 1);
+        load_w(last < cbeg + 1 ? last : cbeg + 1);
 #pragma unroll
         for (int i = 0; i < CT; ++i) *reinterpret_cast<float4*>(&Ws[wlds[i]]) = w0[i];
     }
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = cbeg; c < cend; ++c) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) xc[j] = xn[j];
-        store_w((c + 1) & 1);                                   // chunk c+1 (a harmless repeat after the last one)
+        store_w((c - cbeg + 1) & 1);                            // chunk c+1 (a harmless repeat after the last one)
         load_x(c + 1 < last ? c + 1 : last);
         load_w(c + 2 < last ? c + 2 : last);
-        const float* wb = &Ws[(c & 1) * WBUF + wn * (NT * 1024) + (h * 32 + idx) * 4];
+        const float* wb = &Ws[((c - cbeg) & 1) * WBUF + wn * (NT * 1024) + (h * 32 + idx) * 4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of step j+1 out of step j (registers)
@@ -307,7 +310,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
         }
         __syncthreads();
     }
-    xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope);
+    if (partial)
+        xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, partial + (int64_t)blockIdx.z * m * n, n, nullptr, nullptr, 0,
+                             0, 0.0f);
+    else
+        xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope);
+}
+
+// y = act(sum_z partial[z] + bias + residual): the epilogue of a split-K gemm_xb2 (fixed order over z)
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ partial, int splits, int64_t m, int n,
+                                                               float* __restrict__ y, int64_t ldy, const float* __restrict__ bias,
+                                                               const float* __restrict__ residual, int64_t ldr, int act, float slope)
+{
+    const int n4 = n >> 2;
+    const int64_t total = m * n4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / n4;
+        const int c = (int)(e % n4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(partial + r * n + c);
+        for (int z = 1; z < splits; ++z) {
+            const float4 p = *reinterpret_cast<const float4*>(partial + ((int64_t)z * m + r) * n + c);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (bias) { const float4 bq = *reinterpret_cast<const float4*>(bias + c); v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w; }
+        if (residual) {
+            const float4 rq = *reinterpret_cast<const float4*>(residual + r * ldr + c);
+            v.x += rq.x; v.y += rq.y; v.z += rq.z; v.w += rq.w;
+        }
+        if (act) {
+            v.x = v.x > 0.0f ? v.x : v.x * slope; v.y = v.y > 0.0f ? v.y : v.y * slope;
+            v.z = v.z > 0.0f ? v.z : v.z * slope; v.w = v.w > 0.0f ? v.w : v.w * slope;
+        }
+        *reinterpret_cast<float4*>(y + r * ldy + c) = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -697,9 +732,16 @@ extern "C" {
 int ws_gemm_wave_cols = 0;  // forced wave grid of gemm_xb2 (column groups 1 / 2), 0 = automatic
 int ws_gemm_variant = 2;    // 1 = LDS-staged tiles (gemm_xb / gemm_xty), 2 = operands straight from global memory
 
-int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+int64_t ws_gemm_xb_scratch_bytes(int64_t m, int32_t k, int32_t n)
+{
+    // room for up to 16 split-K partial outputs; only short, deep products use it
+    if (m <= 0 || m >= 32768 || k < 512) return 0;
+    return 16 * m * (int64_t)n * (int64_t)sizeof(float);
+}
+
+static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                         const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
-                        float* y, int64_t ldy, void* stream)
+                        float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream)
 {
     WS_REQUIRE(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
     WS_REQUIRE(!residual || ldr >= n, "residual leading dimension too small");
@@ -715,11 +757,26 @@ int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const
         (!residual || (al16(residual) && ldr % 4 == 0)) && (!bias || al16(bias)) && (int64_t)k * n < (1ll << 29) &&
         128 * ldx < (1ll << 29)) {
 #define WS_XB2(NTV, WNV)                                                                                        \
-    gemm_xb2_kernel<NTV, WNV><<<dim3((unsigned)ws_ceil_div(m, 32 * (4 / WNV)), (unsigned)ws_ceil_div(n, 32 * NTV * WNV)), \
-                                256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, bias, residual, ldr, act, slope)
-        // wave grid: tall operands give every wave its own rows (4 x 1); shorter ones put 2 waves on
-        // the same rows (column groups) so that the launch still fills 256 CUs and the per-wave MFMA
-        // chain k/2 * NT stays short (measured: tools/gemm_lab.cpp)
+    do {                                                                                                        \
+        const unsigned gx2 = (unsigned)ws_ceil_div(m, 32 * (4 / WNV)), gy2 = (unsigned)ws_ceil_div(n, 32 * NTV * WNV); \
+        const int nch = k / 32;                                                                                 \
+        int splits = 1;                                                                                         \
+        if (scratch && (int64_t)gx2 * gy2 < 256 && nch >= 16) {                                                 \
+            splits = (int)ws_ceil_div(768, (int64_t)gx2 * gy2);                                                 \
+            if (splits > nch / 8) splits = nch / 8;                                                             \
+            if (splits > 16) splits = 16;                                                                       \
+            if ((int64_t)splits * m * n * 4 > scratch_bytes) splits = (int)(scratch_bytes / (m * n * 4));       \
+            if (splits < 2) splits = 1;                                                                         \
+        }                                                                                                       \
+        const int csplit = (int)ws_ceil_div(nch, splits);                                                       \
+        splits = (int)ws_ceil_div(nch, csplit);                                                                 \
+        float* part = splits > 1 ? (float*)scratch : nullptr;                                                   \
+        gemm_xb2_kernel<NTV, WNV><<<dim3(gx2, gy2, (unsigned)splits), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, bias, residual, \
+                                                                                    ldr, act, slope, csplit, part);         \
+        if (splits > 1)                                                                                         \
+            splitk_epilogue_kernel<<<ws_grid(m * (n / 4), 256), 256, 0, st>>>(part, splits, m, n, y, ldy, bias, residual, ldr, \
+                                                                              act, slope);                      \
+    } while (0)
         const int64_t tiles = ws_ceil_div(m, 32);
         int wn = tiles >= 2048 ? 1 : 2;
         if (ws_gemm_wave_cols) wn = ws_gemm_wave_cols;
@@ -789,10 +846,24 @@ int ws_act_bwd_colsum(const float* dy, int64_t m, int32_t n, int64_t lddy, const
     return WS_OK;
 }
 
+int ws_gemm_xb_epilogue(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+                        const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
+                        float* y, int64_t ldy, void* stream)
+{
+    return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, nullptr, 0, stream);
+}
+
+int ws_gemm_xb_epilogue_splitk(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+                               const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
+                               float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream)
+{
+    return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream);
+}
+
 int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n, float* y, int64_t ldy,
                void* stream)
 {
-    return ws_gemm_xb_epilogue(x, m, k, ldx, b, n, nullptr, nullptr, 0, 0, 0.0f, y, ldy, stream);
+    return gemm_xb_impl(x, m, k, ldx, b, n, nullptr, nullptr, 0, 0, 0.0f, y, ldy, nullptr, 0, stream);
 }
 
 int64_t ws_gemm_xty_scratch_bytes(int64_t m, int32_t k, int32_t n)

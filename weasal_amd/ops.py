@@ -212,6 +212,8 @@ def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linea
 # ------------------------------------------------------------------------------------------------
 FUSED_EPILOGUE = os.environ.get("WEASAL_FUSED_EPILOGUE", "1") != "0"   # A/B switch (diagnostics)
 GEMM_MIN_ROWS = 4096     # below this the operand is no longer "tall": plain torch.matmul (rocBLAS)
+XTY_MIN_ROWS = 0         # A/B switch: rows below which dW = x^T dy goes to rocBLAS (in the training step the MFMA
+                         # reduction is ahead at every level that reaches it: 0.42 ms vs 0.54 ms per step at M = 10 257)
 
 
 def _gemm_xb(x, b):
@@ -219,8 +221,34 @@ def _gemm_xb(x, b):
     m, k = x.shape
     n = b.shape[1]
     y = torch.empty((m, n), dtype=torch.float32, device=x.device)
-    check(lib.ws_gemm_xb(ptr(x), m, k, x.stride(0), ptr(b), n, ptr(y), n, current_stream()))
+    _xb_launch(lib, x, m, k, b, n, None, None, None, y)
     return y
+
+
+def _xb_launch(lib, x, m, k, b, n, bias, residual, slope, y):
+    """ws_gemm_xb_epilogue, or its split-K form when the product is short and deep (scratch_bytes > 0)"""
+    sb = lib.ws_gemm_xb_scratch_bytes(m, k, n)
+    act, sl = (0, 0.0) if slope is None else (1, float(slope))
+    ldr = residual.stride(0) if residual is not None else 0
+    if sb > 0:
+        scratch = torch.empty(sb, dtype=torch.uint8, device=x.device)
+        check(lib.ws_gemm_xb_epilogue_splitk(ptr(x), m, k, x.stride(0), ptr(b), n, ptr(bias), ptr(residual), ldr, act, sl,
+                                             ptr(y), n, ptr(scratch), sb, current_stream()))
+    else:
+        check(lib.ws_gemm_xb_epilogue(ptr(x), m, k, x.stride(0), ptr(b), n, ptr(bias), ptr(residual), ldr, act, sl,
+                                      ptr(y), n, current_stream()))
+
+
+def _gemm_xty(lib, x, dy):
+    """x^T @ dy: the LDS-free MFMA reduction for tall operands, rocBLAS (TN) for short ones"""
+    m, k = x.shape
+    n = dy.shape[1]
+    if m < XTY_MIN_ROWS:
+        return torch.matmul(x.t(), dy)
+    db = torch.empty((k, n), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(max(lib.ws_gemm_xty_scratch_bytes(m, k, n), 16), dtype=torch.uint8, device=x.device)
+    check(lib.ws_gemm_xty(ptr(x), m, k, x.stride(0), ptr(dy), n, dy.stride(0), ptr(db), ptr(scratch), current_stream()))
+    return db
 
 
 class _MatmulXB(torch.autograd.Function):
@@ -242,12 +270,7 @@ class _MatmulXB(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _gemm_xb(dy, b.t().contiguous())
         if ctx.needs_input_grad[1]:
-            m, k = x.shape
-            n = dy.shape[1]
-            db = torch.empty((k, n), dtype=torch.float32, device=x.device)
-            scratch = torch.empty(max(lib.ws_gemm_xty_scratch_bytes(m, k, n), 16), dtype=torch.uint8, device=x.device)
-            check(lib.ws_gemm_xty(ptr(x), m, k, x.stride(0), ptr(dy), n, dy.stride(0), ptr(db), ptr(scratch),
-                                  current_stream()))
+            db = _gemm_xty(lib, x, dy)
         return dx, db
 
 
@@ -286,9 +309,7 @@ class _MatmulEpilogue(torch.autograd.Function):
         m, k = xc.shape
         n = bc.shape[1]
         y = torch.empty((m, n), dtype=torch.float32, device=x.device)
-        check(lib.ws_gemm_xb_epilogue(ptr(xc), m, k, xc.stride(0), ptr(bc), n, ptr(biasc), ptr(rc),
-                                      rc.stride(0) if rc is not None else 0, 0 if slope is None else 1,
-                                      0.0 if slope is None else float(slope), ptr(y), n, current_stream()))
+        _xb_launch(lib, xc, m, k, bc, n, biasc, rc, slope, y)
         ctx.slope = slope
         ctx.has = (bias is not None, residual is not None)
         ctx.save_for_backward(xc, bc, y if slope is not None else None)
@@ -305,12 +326,7 @@ class _MatmulEpilogue(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _gemm_xb(dz, b.t().contiguous())
         if ctx.needs_input_grad[1]:
-            m, k = x.shape
-            n = dz.shape[1]
-            db = torch.empty((k, n), dtype=torch.float32, device=x.device)
-            scratch = torch.empty(max(lib.ws_gemm_xty_scratch_bytes(m, k, n), 16), dtype=torch.uint8, device=x.device)
-            check(lib.ws_gemm_xty(ptr(x), m, k, x.stride(0), ptr(dz), n, dz.stride(0), ptr(db), ptr(scratch),
-                                  current_stream()))
+            db = _gemm_xty(lib, x, dz)
         if ctx.has[1] and ctx.needs_input_grad[3]:
             dres = dz
         return dx, db, dbias, dres, None
