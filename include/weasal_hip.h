@@ -218,6 +218,26 @@ int ws_radius_neighbors_order(const ws_neighbors_ws* ws, int32_t* out_order, voi
  * Feeds the neighbourhood-limit calibration (datasets/DALES_PseudoLabel.py:1238-1240). */
 const int32_t* ws_radius_neighbors_counts(const ws_neighbors_ws* ws);
 
+/* Table-free backward of self-query KPConv layers (queries == supports): the cell grid of the last search and the
+ * key of the last neighbour kept per query replace the transposed table (ws_transpose_build).
+ *   ws_radius_neighbors_set_key_last  one-shot request: the NEXT search/fill also writes key_last[nq]
+ *                                     = (d2 bits << 32 | index) of the last kept neighbour, ~0 for untruncated rows
+ *   ws_radius_neighbors_grid_info / _grid_export   copy the grid of the last plan (per-element table, cell offsets,
+ *                                     cell-sorted supports) into a caller-owned device blob of `blob_bytes`
+ *   ws_kpconv_gather_bwd_x_grid       = ws_kpconv_gather_bwd_x for q_pts == s_pts, pairs re-derived per support from
+ *                                     that blob: q -> s iff d2 < radius^2 and (d2, s) <= key_last[q]; same pair order,
+ *                                     same sums.  `overflow` (device int32, zero-initialised by the caller) receives the
+ *                                     in-degree of a support with more than 192 incoming pairs (result then invalid);
+ *                                     impossible when the search reported max_count <= 128 for that matrix. */
+int ws_radius_neighbors_set_key_last(ws_neighbors_ws* ws, uint64_t* d_key_last);
+int ws_radius_neighbors_grid_info(const ws_neighbors_ws* ws, int32_t* nb, int64_t* cells, int64_t* ns, int64_t* blob_bytes);
+int ws_radius_neighbors_grid_export(const ws_neighbors_ws* ws, void* blob, void* stream);
+int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                const uint64_t* key_last, float radius, const float* dwf, int32_t ci,
+                                const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                                float extent, int32_t influence, int32_t aggregation, const int32_t* order, float* dx,
+                                int32_t* overflow, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Grid subsampling -- replaces cpp_wrappers/cpp_subsampling (grid_subsampling.subsample_batch /
  * subsample, wrapper.cpp:62-333,338-566 -> grid_subsampling.cpp:5-106,109-211).

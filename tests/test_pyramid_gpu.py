@@ -129,3 +129,41 @@ def test_prefetcher_matches_direct_build(gpu):
         out = [train_step(net, opt, bt, cfg)[0].item() for bt in batches]
         losses.append(out)
     assert np.allclose(losses[0], losses[1], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_grid_backward_matches_transposed_table():
+    """table-free KPConv backward (ws_kpconv_gather_bwd_x_grid) == the transposed-table K4, bit for bit: same
+    pairs, same order, same sums -- on a pyramid whose rows are truncated by the neighbourhood limits"""
+    import numpy as np
+    from weasal_amd import config as wcfg, ops, pyramid, synthetic
+    from weasal_amd.kernel_points import load_kernels
+    dev = torch.device("cuda:0")
+    cfg = wcfg.DALESPLConfig()
+    pts, feats, labels, lens = synthetic.make_inputs(7, 3, 20000, 10.0, cfg.in_features_dim)
+    pts, feats, labels = (torch.from_numpy(a).to(dev) for a in (pts, feats, labels))
+    limits = [20, 30, 40, 40, 30]                 # well below the true counts: truncated rows everywhere
+    batch = pyramid.build_batch(cfg, pts, feats, labels, lens, limits)
+    assert len(batch.search_grids) >= 3
+    batch.activate()
+    torch.manual_seed(0)
+    for l, (inds, grid) in enumerate(batch.search_grids[:3]):
+        p = batch.points[l]
+        assert inds.data_ptr() == batch.neighbors[l].data_ptr()
+        r = cfg.first_subsampling_dl * cfg.conv_radius * 2 ** l
+        kp = torch.from_numpy(load_kernels(r * cfg.KP_extent / cfg.conv_radius * 1.0, 15, dimension=3, fixed="center")
+                              .astype(np.float32)).to(dev) if False else torch.randn(15, 3, device=dev) * (0.6 * r)
+        extent = r * cfg.KP_extent / cfg.conv_radius
+        for ci in (32, 3):
+            x = torch.randn(p.shape[0], ci, device=dev)
+            outs = []
+            for use_grid in (True, False):
+                ops.GRID_BACKWARD = use_grid
+                ops.clear_table_cache()
+                xx = x.clone().requires_grad_(True)
+                wf, _ = ops.kpconv_gather(xx, p, p, inds, kp, extent)
+                wf.backward(torch.ones_like(wf) * 0.5 + wf.detach() * 0.1)
+                outs.append(xx.grad.clone())
+            ops.GRID_BACKWARD = True
+            assert int(grid.overflow.item()) == 0
+            assert torch.equal(outs[0], outs[1]), (l, ci, float((outs[0] - outs[1]).abs().max()))

@@ -10,6 +10,7 @@
 // The structure of K3/K4 (entry pool in LDS, branch-free flush, scheduling order) is described
 // above the kernels.
 #include "ws_common.h"
+#include "ws_grid.h"
 
 namespace {
 
@@ -671,6 +672,213 @@ int check_common(const void* q_pts, int64_t nq, const void* s_pts, int64_t ns, i
     return WS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4 without a transposed table (self-query layers: q_pts == s_pts, the same cloud on both sides).
+// The pairs that reach support s are re-derived from the cell grid the neighbour search built:
+//   q -> s is a pair  <=>  d2(q, s) < r^2  and  (d2(q, s), s) <= key_last[q],
+// key_last[q] being the (distance, index) key of the last neighbour K1 kept in q's row ("infinity" for a
+// row that was not truncated).  The distance is symmetric bit for bit (ws_grid.h: ref_d2), so the wave of s
+// walks the 3x3x3 cell block exactly as K1 does, keeps the candidates that pass the membership test, orders
+// them by index (= ascending pair id, the order of the transposed table, so the sums are the same bits) and
+// runs K4's list / flush on them.  No counting-sort atomics, no scattered fill, no per-list sort: the
+// table build of the big level-0 matrix (1.6 ms per step) disappears.
+// ---------------------------------------------------------------------------------------------
+constexpr int GRID_SLAB = 192;      // incoming pairs per support (the search reports rows up to 128)
+
+template <int K, int G, int MODE, bool VEC>
+__global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
+    const float* __restrict__ s_pts, int64_t ns, const CloudGrid* __restrict__ grids, int nb,
+    const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+    const unsigned long long* __restrict__ key_last, float r2, const float* __restrict__ dwf, int ci,
+    const float* __restrict__ kernel_points, const float* __restrict__ deformed_kp, const float* __restrict__ modulations,
+    GeomParams g, float* __restrict__ dx, const int32_t* __restrict__ order, int32_t* __restrict__ overflow)
+{
+    constexpr int CC = 4 * G;
+    constexpr int S = 64 / G;
+    constexpr int EPL = GRID_SLAB / 64;          // slab entries per lane
+    __shared__ uint2 pool_all[4][POOL_ALLOC];
+    __shared__ int segs_all[4][K + 1];
+    __shared__ float4 slab_all[4][GRID_SLAB];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    uint2* pool = pool_all[wave];
+    int* segs = segs_all[wave];
+    float4* slab = slab_all[wave];
+    const int j = lane % G;
+    const int slot = lane / G;
+    const float inv_extent = 1.0f / g.extent;
+
+    float kpr[MODE == 0 ? 3 * K : 1];
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 3 * K; ++t) kpr[t] = kernel_points[t];
+    }
+
+    int64_t ibeg, iend;
+    ws_block_range(ns, ibeg, iend);
+    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+        const int64_t s = order ? (int64_t)order[item] : item;
+        int b = 0;
+        while (b + 1 < nb && s >= grids[b].s_base + grids[b].s_len) ++b;
+        const CloudGrid gr = grids[b];
+        const float sx = s_pts[3 * s + 0], sy = s_pts[3 * s + 1], sz = s_pts[3 * s + 2];
+        // ---- candidates: the 9 cell runs around s, membership test, compaction into the slab
+        int cnt = 0;
+        auto take = [&](const float4& c, bool active) {
+            // K1 evaluated this pair with c as the query and s as the support: diff = query - support
+            const float d2 = ref_d2(c.x, c.y, c.z, make_float4(sx, sy, sz, 0.0f));
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)s;
+            bool hit = active && d2 < r2;
+            if (hit) hit = key <= key_last[__float_as_int(c.w)];
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = cnt + lane_rank(m);
+                if (pos < GRID_SLAB) slab[pos] = c;
+            }
+            cnt += __builtin_popcountll(m);
+        };
+        if (gr.s_len > 0) {
+            const int cx = cell_coord(sx, gr.lo[0], gr.inv_cell);
+            const int cy = cell_coord(sy, gr.lo[1], gr.inv_cell);
+            const int cz = cell_coord(sz, gr.lo[2], gr.inv_cell);
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gr.nx - 1);
+            int rb[9], re[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+                const bool ok = x0 <= x1 && z >= 0 && z < gr.nz && y >= 0 && y < gr.ny;
+                const int row = gr.cell_base + ((ok ? z : 0) * gr.ny + (ok ? y : 0)) * gr.nx;
+                rb[r] = ok ? cell_start[row + x0] : 0;
+                re[r] = ok ? cell_start[row + x1 + 1] : 0;
+            }
+            float4 c[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int p = rb[r] + lane;
+                c[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < re[r]) c[r] = sorted[p];
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                take(c[r], rb[r] + lane < re[r]);
+                for (int p0 = rb[r] + 64; p0 < re[r]; p0 += 64) {
+                    const int p = p0 + lane;
+                    float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p < re[r]) cc = sorted[p];
+                    take(cc, p < re[r]);
+                }
+            }
+        }
+        if (cnt > GRID_SLAB) {      // cannot happen when the search reported rows <= 128; flagged, never silent
+            if (lane == 0) atomicMax(overflow, cnt);
+            cnt = GRID_SLAB;
+        }
+        wave_lds_sync();
+        // ---- order by index: rank by counting (distinct indices), then permute through registers
+        {
+            float4 e[EPL];
+            int rk[EPL];
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                e[u] = lane + 64 * u < cnt ? slab[lane + 64 * u] : make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
+                rk[u] = 0;
+            }
+            for (int i = 0; i < cnt; ++i) {
+                const int ki = __float_as_int(slab[i].w);
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) rk[u] += ki < __float_as_int(e[u].w) ? 1 : 0;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int u = 0; u < EPL; ++u)
+                if (lane + 64 * u < cnt) slab[rk[u]] = e[u];
+            wave_lds_sync();
+        }
+        // ---- K4's list / flush over the slab
+        for (int cc0 = 0; cc0 < ci; cc0 += CC) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ch = cc0 + 4 * j;
+            const bool chok = VEC ? (ch + 3 < ci) : (ch < ci);
+            const int chl = chok ? ch : 0;
+            auto flush = [&](int total) {
+                wave_lds_sync();
+                total = min(total, POOL);
+                const int per = (total + S - 1) / S;
+                const int lo = slot * per;
+                const int hi = chok ? min(lo + per, total) : lo;
+                for (int it = 0; it < per; it += 4) {
+                    float4 v[4];
+                    float w[4];
+                    uint2 e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        e[u] = pool[min(lo + it + u, POOL + 7)];
+                        keep_unconditional(e[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool ok = lo + it + u < hi;
+                        e[u].x = ok ? e[u].x : 0u;
+                        w[u] = ok ? __uint_as_float(e[u].y) : 0.0f;
+                        v[u] = load_row_piece<VEC>(dwf, e[u].x, ci, chl);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc.x = fmaf(w[u], v[u].x, acc.x);
+                        acc.y = fmaf(w[u], v[u].y, acc.y);
+                        acc.z = fmaf(w[u], v[u].z, acc.z);
+                        acc.w = fmaf(w[u], v[u].w, acc.w);
+                    }
+                }
+                wave_lds_sync();
+            };
+            for (int p0 = 0; p0 < cnt; p0 += 64) {
+                const int p = p0 + lane;
+                const bool real = p < cnt;
+                const float4 c = real ? slab[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int q = real ? __float_as_int(c.w) : 0;
+                const float nx = sx - c.x, ny = sy - c.y, nz = sz - c.z;
+                const float* lkp = deformed_kp ? deformed_kp + (int64_t)q * (3 * K) : kernel_points;
+                const float* lmod = modulations ? modulations + (int64_t)q * K : nullptr;
+                auto kp = [&](int k, int cidx) { return MODE == 0 ? kpr[MODE == 0 ? 3 * k + cidx : 0] : lkp[3 * k + cidx]; };
+                auto nomin = [&](int, float) {};
+                int total = 0, maxlen = 0;
+                kp_list<K, MODE>(nx, ny, nz, real, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod, pool, segs, lane, total,
+                                 maxlen, nomin);
+                if (total <= POOL) {
+                    flush(total);
+                } else {
+                    for (int sub = 0; sub < 4; ++sub) {
+                        total = 0; maxlen = 0;
+                        kp_list<K, MODE>(nx, ny, nz, real && (lane >> 4) == sub, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod,
+                                         pool, segs, lane, total, maxlen, nomin);
+                        flush(total);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o, 64);
+                acc.y += __shfl_xor(acc.y, o, 64);
+                acc.z += __shfl_xor(acc.z, o, 64);
+                acc.w += __shfl_xor(acc.w, o, 64);
+            }
+            if (slot == 0) {
+                float* dst = dx + s * ci + ch;
+                if (VEC) {
+                    if (chok) *reinterpret_cast<float4*>(dst) = acc;
+                } else {
+                    if (ch + 0 < ci) dst[0] = acc.x;
+                    if (ch + 1 < ci) dst[1] = acc.y;
+                    if (ch + 2 < ci) dst[2] = acc.z;
+                    if (ch + 3 < ci) dst[3] = acc.w;
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -767,6 +975,49 @@ int ws_kpconv_gather_bwd_geom(const float* q_pts, int64_t nq, const float* s_pts
     kpconv_gather_bwd_geom_kernel<15><<<ws_grid(nq, 4), 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf,
                                                                        deformed_kp, modulations, d_min_d2, g,
                                                                        d_deformed_kp, d_modulations);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                const uint64_t* key_last, float radius, const float* dwf, int32_t ci,
+                                const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                                float extent, int32_t influence, int32_t aggregation, const int32_t* order, float* dx,
+                                int32_t* overflow, void* stream)
+{
+    int rc = check_common(s_pts, ns, s_pts, ns, 1, ci, k, extent, influence, aggregation);
+    if (rc) return rc;
+    if (ns == 0) return WS_OK;
+    WS_REQUIRE(grid_blob && key_last && dwf && dx && overflow && (kernel_points || deformed_kp), "NULL argument");
+    WS_REQUIRE(nb >= 1 && cells >= 1, "bad grid nb=%d cells=%lld", nb, (long long)cells);
+    WS_REQUIRE(ns * (int64_t)k * ci < (1ll << 31), "ns*k*ci exceeds the 32-bit row offsets of the gather");
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
+    hipStream_t st = (hipStream_t)stream;
+    const char* base = (const char*)grid_blob;
+    const CloudGrid* grids = (const CloudGrid*)base;
+    const int32_t* cell_start = (const int32_t*)(base + ws_grid_blob_cells_off(nb));
+    const float4* sorted = (const float4*)(base + ws_grid_blob_sorted_off(nb, cells));
+    const float r2 = radius * radius;                       // neighbors.cpp:226, as in the search
+    const unsigned long long* kl = reinterpret_cast<const unsigned long long*>(key_last);
+    const int grid = ws_grid(ns, 4);
+    const int vec4 = (ci % 4 == 0) && aligned16(dwf) && aligned16(dx);
+#define WS_BWDG2(G, MODEV, VECV)                                                                                     \
+    kpconv_gather_bwd_x_grid_kernel<15, G, MODEV, VECV><<<grid, 256, 0, st>>>(s_pts, ns, grids, nb, cell_start, sorted, kl, r2, \
+                                                                              dwf, ci, kernel_points, deformed_kp,    \
+                                                                              modulations, g, dx, order, overflow)
+#define WS_BWDG(G)                                                                      \
+    do {                                                                                \
+        if (fast) { if (vec4) WS_BWDG2(G, 0, true); else WS_BWDG2(G, 0, false); }        \
+        else { if (vec4) WS_BWDG2(G, 1, true); else WS_BWDG2(G, 1, false); }             \
+    } while (0)
+    const bool fast = !deformed_kp && !modulations && influence == WS_INFLUENCE_LINEAR && aggregation == WS_AGGREGATION_SUM;
+    if (ci <= 4) WS_BWDG(1);
+    else if (ci <= 8) WS_BWDG(2);
+    else if (ci <= 16) WS_BWDG(4);
+    else if (ci <= 32) WS_BWDG(8);
+    else WS_BWDG(16);
+#undef WS_BWDG2
+#undef WS_BWDG
     WS_LAUNCH_CHECK();
     return WS_OK;
 }

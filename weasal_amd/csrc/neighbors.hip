@@ -14,19 +14,10 @@
 // Pass A (plan) only counts (-> max_count, the data-dependent width, neighbors.cpp:296-304),
 // pass B (fill) sorts and writes int32 or int64 rows padded with ns (neighbors.cpp:324).
 #include "ws_scan.h"
+#include "ws_grid.h"
 #include <vector>
 
 namespace {
-
-struct CloudGrid {        // one per batch element, device resident
-    float lo[3];
-    float inv_cell;
-    int nx, ny, nz;
-    int cell_base;        // first cell of this element in the global cell arrays
-    int cell_cap;         // cells reserved for this element
-    int s_base, s_len;
-    int q_base, q_len;
-};
 
 __global__ __launch_bounds__(1024) void nb_bbox_kernel(const float* __restrict__ pts, CloudGrid* __restrict__ grids,
                                                         float* __restrict__ bbox /*[nb][6]*/)
@@ -96,13 +87,6 @@ __global__ void nb_grid_setup_kernel(CloudGrid* __restrict__ grids, const float*
     grids[b] = g;
 }
 
-// cell coordinate; clamped so that far-away queries cannot overflow the int conversion
-__device__ __forceinline__ int cell_coord(float v, float lo, float inv)
-{
-    const float t = floorf((v - lo) * inv);
-    return (int)fminf(fmaxf(t, -2.0f), 1.0e6f);
-}
-
 // one thread per support: cell id + histogram
 __global__ __launch_bounds__(256) void nb_bin_count_kernel(const float* __restrict__ pts, const CloudGrid* __restrict__ grids,
                                                             int nb, int64_t ns, int32_t* __restrict__ cell_of,
@@ -167,16 +151,6 @@ __device__ __forceinline__ int find_cloud_q(const CloudGrid* __restrict__ grids,
     return b;
 }
 
-// exact reference recipe (nanoflann.hpp:432-440): result = 0; result += diff*diff, diff = query - support
-__device__ __forceinline__ float ref_d2(float qx, float qy, float qz, const float4& c)
-{
-    const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-    float r = dx * dx;
-    r = r + dy * dy;
-    r = r + dz * dz;
-    return r;
-}
-
 __global__ __launch_bounds__(256) void nb_count_kernel(const float* __restrict__ queries, int64_t nq,
                                                         const CloudGrid* __restrict__ grids, int nb,
                                                         const int32_t* __restrict__ cell_start,
@@ -212,7 +186,8 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
                                                        const int32_t* __restrict__ cell_start,
                                                        const float4* __restrict__ sorted, float r2, int64_t ns,
                                                        int width, const int32_t* __restrict__ qorder, OutT* __restrict__ out,
-                                                       int32_t* __restrict__ counts, int32_t* __restrict__ max_count)
+                                                       int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
+                                                       unsigned long long* __restrict__ key_last)
 {
     __shared__ unsigned long long slab_all[4][CAP];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -267,6 +242,8 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
         }
         for (int j = lane; j < width; j += 64)
             out[q * width + j] = j < cnt ? (OutT)(unsigned)(slab[j] & 0xffffffffull) : (OutT)ns;
+        // key of the last neighbour kept when the row is truncated, "infinity" when every neighbour is kept
+        if (key_last && lane == 0) key_last[q] = cnt > width ? slab[width - 1] : ~0ull;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -285,7 +262,8 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
                                                           const int32_t* __restrict__ cell_start,
                                                           const float4* __restrict__ sorted, float r2, int64_t ns,
                                                           int width, const int32_t* __restrict__ qorder, OutT* __restrict__ out,
-                                                          int32_t* __restrict__ counts, int32_t* __restrict__ max_count)
+                                                          int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
+                                                          unsigned long long* __restrict__ key_last)
 {
     constexpr int CAP = 128;
     __shared__ unsigned long long slab_all[4][CAP];
@@ -371,6 +349,14 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
         if (lane < cnt && ra < width) orow[ra] = (OutT)(unsigned)(a & 0xffffffffull);
         if (lane + 64 < cnt && rb < width) orow[rb] = (OutT)(unsigned)(bkey & 0xffffffffull);
         for (int j = cnt + lane; j < width; j += 64) orow[j] = (OutT)ns;
+        if (key_last) {     // the key at sorted position width-1 of a truncated row, "infinity" otherwise
+            if (cnt > width) {
+                if (lane < cnt && ra == width - 1) key_last[q] = a;
+                if (lane + 64 < cnt && rb == width - 1) key_last[q] = bkey;
+            } else if (lane == 0) {
+                key_last[q] = ~0ull;
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -415,6 +401,8 @@ struct ws_neighbors_ws {
     int nb = 0;
     float r2 = 0.f;
     int max_count_host = 0;
+    int64_t cells = 0;                         // cells of the last plan (all elements)
+    unsigned long long* key_last = nullptr;    // one-shot output of the next fill (ws_radius_neighbors_set_key_last)
 };
 
 extern "C" {
@@ -500,7 +488,7 @@ static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, con
     nb_order_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(ws->sorted.p, ns, ws->order.p);
     WS_LAUNCH_CHECK();
     ws->self_query = (queries == supports && nq == ns);
-    ws->queries = queries; ws->nq = nq; ws->ns = ns; ws->nb = nb;
+    ws->queries = queries; ws->nq = nq; ws->ns = ns; ws->nb = nb; ws->cells = cells;
     ws->r2 = radius * radius;   // neighbors.cpp:226
     return WS_OK;
 }
@@ -526,6 +514,12 @@ int ws_radius_neighbors_plan(ws_neighbors_ws* ws, const float* queries, int64_t 
     return WS_OK;
 }
 
+// the key_last request is one-shot: cleared when the public entry that consumed it returns
+struct KeyLastGuard {
+    ws_neighbors_ws* ws;
+    ~KeyLastGuard() { if (ws) ws->key_last = nullptr; }
+};
+
 static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* out_i32, int64_t* out_i64,
                           bool with_counts, hipStream_t st)
 {
@@ -533,22 +527,23 @@ static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* 
     const int32_t* qo = ws->self_query ? ws->order.p : nullptr;
     int32_t* cn = with_counts ? ws->counts.p : nullptr;
     int32_t* mx = with_counts ? ws->max_count.p : nullptr;
+    unsigned long long* kl = ws->key_last;
 #define WS_NB_FILL(CAP)                                                                                            \
     do {                                                                                                           \
         if (out_i32)                                                                                               \
             nb_fill_kernel<CAP, int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p, \
-                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i32, cn, mx);  \
+                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i32, cn, mx, kl);  \
         else                                                                                                       \
             nb_fill_kernel<CAP, int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p, \
-                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx);  \
+                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx, kl);  \
     } while (0)
     if (cap <= 128) {
         if (out_i32)
             nb_fill128_kernel<int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
-                                                             ws->sorted.p, ws->r2, ws->ns, width, qo, out_i32, cn, mx);
+                                                             ws->sorted.p, ws->r2, ws->ns, width, qo, out_i32, cn, mx, kl);
         else
             nb_fill128_kernel<int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
-                                                             ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx);
+                                                             ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx, kl);
     }
     else if (cap <= 512) WS_NB_FILL(512);
     else if (cap <= 2048) WS_NB_FILL(2048);
@@ -563,6 +558,7 @@ int ws_radius_neighbors_search(ws_neighbors_ws* ws, const float* queries, int64_
                                float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
                                int32_t* h_max_count, void* stream)
 {
+    KeyLastGuard guard{ws};
     WS_REQUIRE(h_max_count, "NULL argument");
     WS_REQUIRE((out_i32 != nullptr) != (out_i64 != nullptr), "exactly one of out_i32 / out_i64 must be given");
     WS_REQUIRE(width >= 1, "width must be >= 1");
@@ -590,6 +586,7 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, 
                                      float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
                                      int32_t* d_max_count, void* stream)
 {
+    KeyLastGuard guard{ws};
     WS_REQUIRE(d_max_count, "NULL argument");
     WS_REQUIRE((out_i32 != nullptr) != (out_i64 != nullptr), "exactly one of out_i32 / out_i64 must be given");
     WS_REQUIRE(width >= 1, "width must be >= 1");
@@ -605,6 +602,7 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, 
 
 int ws_radius_neighbors_fill(ws_neighbors_ws* ws, int32_t width, int32_t* out_i32, int64_t* out_i64, void* stream)
 {
+    KeyLastGuard guard{ws};
     WS_REQUIRE(ws && ws->nq > 0 && ws->max_count_host > 0, "no successful plan to fill from");
     WS_REQUIRE((out_i32 != nullptr) != (out_i64 != nullptr), "exactly one of out_i32 / out_i64 must be given");
     WS_REQUIRE(width >= 1 && width <= ws->max_count_host, "width %d outside [1, max_count=%d]", width, ws->max_count_host);
@@ -619,5 +617,33 @@ int ws_radius_neighbors_order(const ws_neighbors_ws* ws, int32_t* out_order, voi
 }
 
 const int32_t* ws_radius_neighbors_counts(const ws_neighbors_ws* ws) { return ws ? ws->counts.p : nullptr; }
+
+int ws_radius_neighbors_set_key_last(ws_neighbors_ws* ws, uint64_t* d_key_last)
+{
+    WS_REQUIRE(ws, "NULL argument");
+    ws->key_last = reinterpret_cast<unsigned long long*>(d_key_last);
+    return WS_OK;
+}
+
+int ws_radius_neighbors_grid_info(const ws_neighbors_ws* ws, int32_t* nb, int64_t* cells, int64_t* ns, int64_t* blob_bytes)
+{
+    WS_REQUIRE(ws && ws->nq > 0 && nb && cells && ns && blob_bytes, "no plan / NULL argument");
+    *nb = ws->nb; *cells = ws->cells; *ns = ws->ns;
+    *blob_bytes = ws_grid_blob_bytes(ws->nb, ws->cells, ws->ns);
+    return WS_OK;
+}
+
+int ws_radius_neighbors_grid_export(const ws_neighbors_ws* ws, void* blob, void* stream)
+{
+    WS_REQUIRE(ws && ws->nq > 0 && blob, "no plan / NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)blob;
+    WS_HIP(hipMemcpyAsync(base, ws->grids.p, sizeof(CloudGrid) * (size_t)ws->nb, hipMemcpyDeviceToDevice, st));
+    WS_HIP(hipMemcpyAsync(base + ws_grid_blob_cells_off(ws->nb), ws->cell_start.p, sizeof(int32_t) * (size_t)(ws->cells + 2),
+                          hipMemcpyDeviceToDevice, st));
+    WS_HIP(hipMemcpyAsync(base + ws_grid_blob_sorted_off(ws->nb, ws->cells), ws->sorted.p, sizeof(float4) * (size_t)ws->ns,
+                          hipMemcpyDeviceToDevice, st));
+    return WS_OK;
+}
 
 }  // extern "C"

@@ -129,6 +129,32 @@ def set_point_orders(pairs):
         _orders[points.data_ptr()] = order
 
 
+# grids of self-query searches (table-free KPConv backward): key = the index matrix the blocks pass in
+GRID_BACKWARD = os.environ.get("WEASAL_GRID_BACKWARD", "1") != "0"   # A/B switch (diagnostics, tests)
+_grids = {}
+
+
+class SearchGrid:
+    """What ws_kpconv_gather_bwd_x_grid needs of one self-query search: the exported cell grid, the key of the
+    last kept neighbour per query, the radius; `overflow` is the kernel's (never expected) capacity flag."""
+    __slots__ = ("blob", "nb", "cells", "ns", "key_last", "radius", "overflow")
+
+    def tensors(self):
+        return (self.blob, self.key_last, self.overflow)
+
+
+def set_search_grids(pairs):
+    """install the (index matrix, SearchGrid) pairs of the batch about to be trained on (PyramidBatch.activate)"""
+    _grids.clear()
+    for inds, grid in pairs:
+        _grids[(inds.data_ptr(), tuple(inds.shape))] = (inds, grid)
+
+
+def _grid_for(inds):
+    hit = _grids.get((inds.data_ptr(), tuple(inds.shape))) if GRID_BACKWARD else None
+    return hit[1] if hit is not None else None
+
+
 def _order_for(points):
     o = _orders.get(points.data_ptr())
     if o is not None and o.numel() == points.shape[0] and o.device == points.device:
@@ -176,13 +202,22 @@ class _KPConvGather(torch.autograd.Function):
         dwf = dwf.contiguous()
         dx = d_dkp = d_mod = None
         if ctx.needs_input_grad[0]:
-            table = transposed_table(inds, ns)
             dx = torch.empty_like(x)
+            grid = _grid_for(inds) if (nq == ns and q_pts.data_ptr() == s_pts.data_ptr()) else None
             tok = _tbegin("kpconv_gather_bwd_x", nq, h, ci)
-            check(lib.ws_kpconv_gather_bwd_x(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(table.offsets),
-                                             ptr(table.pairs), ptr(dwf), ci, ptr(kernel_points), k, ptr(dkp),
-                                             ptr(mod), extent, influence, aggregation, ptr(_order_for(s_pts)),
-                                             ptr(dx), current_stream()))
+            if grid is not None and grid.ns == ns:
+                # self-query layer: incoming pairs re-derived from the search grid, no transposed table
+                check(lib.ws_kpconv_gather_bwd_x_grid(ptr(s_pts), ns, ptr(grid.blob), grid.nb, grid.cells,
+                                                      ptr(grid.key_last), grid.radius, ptr(dwf), ci, ptr(kernel_points), k,
+                                                      ptr(dkp), ptr(mod), extent, influence, aggregation,
+                                                      ptr(_order_for(s_pts)), ptr(dx), ptr(grid.overflow),
+                                                      current_stream()))
+            else:
+                table = transposed_table(inds, ns)
+                check(lib.ws_kpconv_gather_bwd_x(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(table.offsets),
+                                                 ptr(table.pairs), ptr(dwf), ci, ptr(kernel_points), k, ptr(dkp),
+                                                 ptr(mod), extent, influence, aggregation, ptr(_order_for(s_pts)),
+                                                 ptr(dx), current_stream()))
             _tend(tok)
         if dkp is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             d_dkp = torch.empty_like(dkp)
@@ -556,7 +591,10 @@ class DeferredSearches:
         self.slots = torch.zeros(capacity, dtype=torch.int32, device=device)
         self.calls = []
 
-    def add(self, queries, supports, q_lens, s_lens, radius, limit, want_order=False):
+    def add(self, queries, supports, q_lens, s_lens, radius, limit, want_order=False, want_grid=False):
+        """-> index matrix; with want_order / want_grid: (matrix, cell order or None, SearchGrid or None).
+        The grid is only meaningful for a self-query (queries is supports) and while `counts()` of this call
+        stays <= 128 (checked by the caller after finish())."""
         import ctypes as C
         lib = _lib.lib()
         q, s = _f32c(queries), _f32c(supports)
@@ -569,7 +607,14 @@ class DeferredSearches:
         width = max(1, int(limit))
         out = torch.empty((q.shape[0], width), dtype=torch.int64, device=q.device)
         slot = len(self.calls)
+        grid = None
         with torch.cuda.device(q.device):
+            if want_grid:
+                grid = SearchGrid()
+                grid.key_last = torch.empty((q.shape[0],), dtype=torch.int64, device=q.device)
+                grid.radius = float(np.float32(radius))
+                grid.overflow = torch.zeros((1,), dtype=torch.int32, device=q.device)
+                check(lib.ws_radius_neighbors_set_key_last(ws, ptr(grid.key_last)))
             check(lib.ws_radius_neighbors_search_async(
                 ws, ptr(q), q.shape[0], ptr(s), s.shape[0], C.c_void_p(ql.ctypes.data), C.c_void_p(sl.ctypes.data),
                 ql.shape[0], float(np.float32(radius)), width, None, ptr(out),
@@ -578,11 +623,20 @@ class DeferredSearches:
             if want_order:
                 order = torch.empty(s.shape[0], dtype=torch.int32, device=q.device)
                 check(lib.ws_radius_neighbors_order(ws, ptr(order), current_stream()))
+            if want_grid:
+                nb, cells, ns_, nbytes = C.c_int32(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+                check(lib.ws_radius_neighbors_grid_info(ws, C.byref(nb), C.byref(cells), C.byref(ns_), C.byref(nbytes)))
+                grid.blob = torch.empty((nbytes.value,), dtype=torch.uint8, device=q.device)
+                grid.nb, grid.cells, grid.ns = nb.value, cells.value, ns_.value
+                check(lib.ws_radius_neighbors_grid_export(ws, ptr(grid.blob), current_stream()))
         self.calls.append((out, (q, s, ql, sl, radius, width)))
+        if want_grid:
+            return out, order, grid
         return (out, order) if want_order else out
 
     def finish(self):
         counts = self.slots[:len(self.calls)].cpu().numpy() if self.calls else []
+        self.last_counts = [int(c) for c in counts]      # true maximum row length of every call, in order
         final = []
         for (out, args), mc in zip(self.calls, counts):
             q, s, ql, sl, radius, width = args

@@ -43,7 +43,7 @@ def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_gr
 
 
 def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_lengths,
-                        neighborhood_limits=(), random_grid_orient=True, point_orders=None):
+                        neighborhood_limits=(), random_grid_orient=True, point_orders=None, search_grids=None):
     """-> flat list  points[L] + neighbors[L] + pools[L] + upsamples[L] + lengths[L] + [features, labels]
     (datasets/common.py:574-575), all device tensors (lengths int32, indices int64).
 
@@ -58,6 +58,7 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
     limits = list(neighborhood_limits)
     deferred = ops.DeferredSearches(dev) if len(limits) > 0 else None
     slots = []   # (list, position) of every deferred matrix
+    pending_grids = []   # (slot index, SearchGrid) of the self-query searches (table-free KPConv backward)
 
     def search(q, s, ql, sl, r, layer, register_order=False):
         if deferred is None:
@@ -67,8 +68,12 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
             orders.append((s, order))
             return inds
         if register_order:
-            inds, order = deferred.add(q, s, ql, sl, r, limits[layer], want_order=True)
+            want_grid = search_grids is not None and q is s
+            res = deferred.add(q, s, ql, sl, r, limits[layer], want_order=True, want_grid=want_grid)
+            inds, order = res[0], res[1]
             orders.append((s, order))
+            if want_grid:
+                pending_grids.append((len(slots), res[2]))
             return inds
         return deferred.add(q, s, ql, sl, r, limits[layer])
 
@@ -117,8 +122,14 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
         if 'global' in block or 'upsample' in block:
             break
     if deferred is not None:
-        for (lst, pos), mat in zip(slots, deferred.finish()):
+        final = deferred.finish()
+        for (lst, pos), mat in zip(slots, final):
             lst[pos] = mat
+        for slot, grid in pending_grids:
+            # usable while no row of that search exceeded the 128-entry fast path (then the in-degree of a
+            # support is bounded by it as well); otherwise the layer keeps the transposed-table backward
+            if 0 < deferred.last_counts[slot] <= 128:
+                search_grids.append((final[slot], grid))
     # the per-layer lengths go to the device in ONE copy (views of it are handed out)
     sizes = [len(a) for a in input_lengths]
     all_lens = torch.from_numpy(np.concatenate(input_lengths).astype(np.int32)).to(dev)
@@ -146,6 +157,7 @@ class PyramidBatch:
         if extra == 7:
             self.scales, self.rots, self.cloud_inds, self.center_inds, self.input_inds = input_list[5 * L + 2:5 * L + 7]
         self.point_orders = list(point_orders)   # [(points tensor, cell-order permutation)]: scheduling hints
+        self.search_grids = []                   # [(index matrix, ops.SearchGrid)]: table-free backward of self-query layers
         self.tables = []                         # pre-built transposed tables [(inds, ns, table)] (build_tables)
         self.col0_tables = []
         self.ready = None                        # event recorded on the stream that built the batch
@@ -160,6 +172,9 @@ class PyramidBatch:
         for _, _, tb in self.tables + self.col0_tables:
             yield tb.offsets
             yield tb.pairs
+        for _, grid in self.search_grids:
+            for t in grid.tensors():
+                yield t
 
     def build_tables(self):
         """Transposed neighbour tables every backward of this batch needs (KPConv dX over neighbors[l] /
@@ -167,9 +182,12 @@ class PyramidBatch:
         stream that builds the batch -- they are off the training stream's critical path."""
         self.tables, self.col0_tables = [], []
         L = len(self.points)
+        have_grid = {m.data_ptr() for m, _ in self.search_grids} if ops.GRID_BACKWARD else set()
         for l in range(L):
             ns = self.points[l].shape[0]
             for mat in (self.neighbors[l], self.pools[l]):
+                if mat.data_ptr() in have_grid:
+                    continue         # KPConv is the only reader of neighbors[l] and goes through the grid
                 if mat.shape[0] > 0 and mat.is_cuda:
                     self.tables.append((mat, ns, ops.TransposedTable(mat, ns)))
             up = self.upsamples[l]
@@ -207,6 +225,7 @@ class PyramidBatch:
                         t.record_stream(stream)
                 self.ready = None
             ops.set_point_orders(self.point_orders)
+            ops.set_search_grids(self.search_grids)
             ops.clear_table_cache()              # tables belong to one batch
             ops.install_tables(self.tables, self.col0_tables)
         return self
@@ -214,10 +233,11 @@ class PyramidBatch:
 
 def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True,
                 with_tables=True):
-    orders = []
+    orders, grids = [], []
     li = segmentation_inputs(config, points, features, labels, lengths, neighborhood_limits, random_grid_orient,
-                             point_orders=orders)
+                             point_orders=orders, search_grids=grids if points.is_cuda else None)
     batch = PyramidBatch(li, orders)
+    batch.search_grids = grids
     if with_tables and points.is_cuda:
         batch.build_tables()
     if points.is_cuda:
