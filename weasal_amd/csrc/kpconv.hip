@@ -243,7 +243,7 @@ __device__ __forceinline__ void kp_list2(float ax, float ay, float az, bool aliv
 // accumulate onto the rows already written.  The index and xyz loads of the next two items are
 // software-prefetched under the current item.
 // ---------------------------------------------------------------------------------------------
-template <int K, int G, int MODE, bool DEF, bool VEC>
+template <int K, int G, int MODE, bool DEF, bool VEC, int PW = 4>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     float* __restrict__ min_d2, const int32_t* __restrict__ order)
 {
     static_assert(!(DEF && MODE == 0), "deformable layers use MODE 1");
-    constexpr int CC = 4 * G;      // channels per chunk
+    static_assert(PW == 4 || (PW == 1 && !VEC), "piece width: 16 bytes, or one float for the 3-channel input layer");
+    constexpr int CC = PW * G;     // channels per chunk (PW = 1: lane = (kernel point, channel), 4-byte pieces)
     constexpr int S = 64 / G;      // entry slots
     constexpr int KPS = (K + S - 1) / S;   // kernel points per slot
     static_assert(K <= 16 && POOL >= 16 * K, "pool sizing");
@@ -280,6 +281,48 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     // maxlen = longest segment (wave-uniform): every round runs that many steps.
     auto flush = [&](int64_t q, bool accumulate, int maxlen) {
         wave_lds_sync();
+        if (PW == 1) {
+            // narrow rows (the 3-channel input layer): one float per lane, a slot of G lanes per kernel point --
+            // 45 of 64 lanes busy with one 4-byte load per entry instead of 15 lanes with four clamped loads
+            for (int cc0 = 0; cc0 < ci; cc0 += CC) {
+                const int ch = cc0 + j;
+                const bool chok = ch < ci;
+                const int chl = chok ? ch : 0;
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk) {
+                    const int k = slot + kk * S;
+                    const bool kok = k < K && chok;
+                    const int beg = kok ? segs[k] : 0;
+                    const int end = kok ? min(segs[k + 1], POOL) : 0;
+                    float a = 0.0f;
+                    for (int it = 0; it < maxlen; it += 4) {
+                        uint2 e[4];
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            e[u] = pool[min(beg + it + u, POOL + 7)];
+                            keep_unconditional(e[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool ok = beg + it + u < end;
+                            e[u].x = ok ? e[u].x : 0u;
+                            e[u].y = ok ? e[u].y : 0u;
+                            v[u] = x[(size_t)(e[u].x * (unsigned)ci) + chl];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a = fmaf(__uint_as_float(e[u].y), v[u], a);
+                    }
+                    if (kok) {
+                        if (modulations) a *= modulations[q * K + k];
+                        float* dst = wf + (q * K + k) * ci + ch;
+                        *dst = (accumulate ? *dst : 0.f) + a;
+                    }
+                }
+            }
+            wave_lds_sync();
+            return;
+        }
         for (int cc0 = 0; cc0 < ci; cc0 += CC) {
             const int ch = cc0 + 4 * j;
             const bool chok = VEC ? (ch + 3 < ci) : (ch < ci);
@@ -909,7 +952,18 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
         else { if (vec4) WS_FWD2(G, 1, false, true); else WS_FWD2(G, 1, false, false); }            \
     } while (0)
     const bool fast = influence == WS_INFLUENCE_LINEAR && aggregation == WS_AGGREGATION_SUM;
-    if (ci <= 4) WS_FWD(1);
+    if (ci <= 4 && !vec4) {
+        // narrow rows that are not float4 (the 3-channel input layer): 4-byte pieces, 16 slots of 4 lanes
+#define WS_FWDN(MODEV, DEFV)                                                                                          \
+    kpconv_gather_fwd_kernel<15, 4, MODEV, DEFV, false, 1><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,  \
+                                                                                 kernel_points, deformed_kp, modulations, \
+                                                                                 g, wf, min_d2, order)
+        if (deformed_kp) WS_FWDN(1, true);
+        else if (fast) WS_FWDN(0, false);
+        else WS_FWDN(1, false);
+#undef WS_FWDN
+    }
+    else if (ci <= 4) WS_FWD(1);
     else if (ci <= 8) WS_FWD(2);
     else if (ci <= 16) WS_FWD(4);
     else if (ci <= 32) WS_FWD(8);
