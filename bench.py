@@ -179,13 +179,15 @@ def main():
         loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync, epoch=0 if args.contrast else None)
         return loss
 
-    # Runtime warm-up, untimed and before the W warm-up steps: the HIP runtime grows its launch
-    # bookkeeping (signal / kernarg pools) once, after roughly ten un-synchronised steps' worth of
-    # queued launches -- a single 60-80 ms stall that tools/step_timing_diag.py shows at step 9 and
-    # that is unrelated to the kernels.  Keep it out of both the warm-up and the timed region.
+    # Untimed pre-warm before the W warm-up steps (allocator caches, lazy module loads), then the training
+    # loop's usual garbage-collector hygiene: without gc.freeze() CPython's full collection walks the module
+    # tree and the autograd graphs for 80-90 ms at about the 17th step of a fresh process
+    # (tools/stall_diag.py) -- a host stall, unrelated to the kernels, that drains the launch queue.
+    from weasal_amd.trainer import freeze_gc
     for i in range(max(0, 12 - args.warmup)):
         step(i)
     torch.cuda.synchronize()
+    freeze_gc()
     for i in range(args.warmup):
         tw = time.perf_counter()
         step(i)
