@@ -402,6 +402,7 @@ struct ws_neighbors_ws {
     float r2 = 0.f;
     int max_count_host = 0;
     int64_t cells = 0;                         // cells of the last plan (all elements)
+    int32_t* max_count_word = nullptr;         // device word holding the maximum row length of the current plan
     unsigned long long* key_last = nullptr;    // one-shot output of the next fill (ws_radius_neighbors_set_key_last)
 };
 
@@ -477,8 +478,9 @@ static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, con
     WS_LAUNCH_CHECK();
     nb_grid_setup_kernel<<<(nb + 63) / 64, 64, 0, st>>>(ws->grids.p, ws->bbox.p, nb, radius);
     WS_LAUNCH_CHECK();
+    // one memset clears the cell histogram AND the max-count word (kept in the spare slot behind the scan output)
     WS_HIP(hipMemsetAsync(ws->cell_start.p, 0, sizeof(int32_t) * (size_t)(cells + 2), st));
-    WS_HIP(hipMemsetAsync(ws->max_count.p, 0, sizeof(int32_t), st));
+    ws->max_count_word = ws->cell_start.p + cells + 1;
     nb_bin_count_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(supports, ws->grids.p, nb, ns, ws->cell_of.p, ws->cell_start.p);
     WS_LAUNCH_CHECK();
     if ((rc = ws_exclusive_scan_i32(ws->cell_start.p, ws->cell_start.p, cells, ws->scan_scratch.p, st))) return rc;
@@ -503,10 +505,10 @@ int ws_radius_neighbors_plan(ws_neighbors_ws* ws, const float* queries, int64_t 
     int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
     if (rc) { if (ws) ws->nq = 0; return rc; }
     nb_count_kernel<<<ws_grid(nq, 4), 256, 0, st>>>(queries, nq, ws->grids.p, nb, ws->cell_start.p, ws->sorted.p, ws->r2,
-                                                    ws->self_query ? ws->order.p : nullptr, ws->counts.p, ws->max_count.p);
+                                                    ws->self_query ? ws->order.p : nullptr, ws->counts.p, ws->max_count_word);
     WS_LAUNCH_CHECK();
     int32_t mc = 0;
-    WS_HIP(hipMemcpyAsync(&mc, ws->max_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    WS_HIP(hipMemcpyAsync(&mc, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     WS_HIP(hipStreamSynchronize(st));
     ws->max_count_host = mc;
     *h_max_count = mc;
@@ -526,7 +528,7 @@ static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* 
     const int grid = ws_grid(ws->nq, 4);
     const int32_t* qo = ws->self_query ? ws->order.p : nullptr;
     int32_t* cn = with_counts ? ws->counts.p : nullptr;
-    int32_t* mx = with_counts ? ws->max_count.p : nullptr;
+    int32_t* mx = with_counts ? ws->max_count_word : nullptr;
     unsigned long long* kl = ws->key_last;
 #define WS_NB_FILL(CAP)                                                                                            \
     do {                                                                                                           \
@@ -568,10 +570,10 @@ int ws_radius_neighbors_search(ws_neighbors_ws* ws, const float* queries, int64_
     if (rc) { if (ws) ws->nq = 0; return rc; }
     int cap = 128;
     for (;;) {
-        WS_HIP(hipMemsetAsync(ws->max_count.p, 0, sizeof(int32_t), st));
+        WS_HIP(hipMemsetAsync(ws->max_count_word, 0, sizeof(int32_t), st));
         if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st))) return rc;
         int32_t mc = 0;
-        WS_HIP(hipMemcpyAsync(&mc, ws->max_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        WS_HIP(hipMemcpyAsync(&mc, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         WS_HIP(hipStreamSynchronize(st));
         ws->max_count_host = mc;
         *h_max_count = mc;
@@ -593,9 +595,8 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, 
     hipStream_t st = (hipStream_t)stream;
     int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
     if (rc) { if (ws) ws->nq = 0; return rc; }
-    WS_HIP(hipMemsetAsync(ws->max_count.p, 0, sizeof(int32_t), st));
-    if ((rc = nb_launch_fill(ws, 128, width, out_i32, out_i64, true, st))) return rc;
-    WS_HIP(hipMemcpyAsync(d_max_count, ws->max_count.p, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if ((rc = nb_launch_fill(ws, 128, width, out_i32, out_i64, true, st))) return rc;   // max-count word cleared by nb_prepare
+    WS_HIP(hipMemcpyAsync(d_max_count, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     ws->max_count_host = 128;   // unknown on the host; rows beyond 128 are reported through d_max_count
     return WS_OK;
 }
