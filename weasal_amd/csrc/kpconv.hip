@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
     constexpr int EPL = GRID_SLAB / 64;          // slab entries per lane
     __shared__ uint2 pool_all[4][POOL_ALLOC];
     __shared__ int segs_all[4][K + 1];
-    __shared__ float4 slab_all[4][GRID_SLAB];
+    __shared__ float4 slab_all[4][GRID_SLAB + 64];      // + one dummy slot per lane (unconditional writes)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     uint2* pool = pool_all[wave];
@@ -759,11 +759,14 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
 
     int64_t ibeg, iend;
     ws_block_range(ns, ibeg, iend);
+    CloudGrid gr = grids[0];        // supports come cloud by cloud: the element's grid stays in registers
     for (int64_t item = ibeg + wave; item < iend; item += 4) {
         const int64_t s = order ? (int64_t)order[item] : item;
-        int b = 0;
-        while (b + 1 < nb && s >= grids[b].s_base + grids[b].s_len) ++b;
-        const CloudGrid gr = grids[b];
+        if (s < gr.s_base || s >= gr.s_base + gr.s_len) {
+            int b = 0;
+            while (b + 1 < nb && s >= grids[b].s_base + grids[b].s_len) ++b;
+            gr = grids[b];
+        }
         const float sx = s_pts[3 * s + 0], sy = s_pts[3 * s + 1], sz = s_pts[3 * s + 2];
         // ---- candidates: the 9 cell runs around s, membership test, compaction into the slab
         int cnt = 0;
@@ -772,12 +775,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
             const float d2 = ref_d2(c.x, c.y, c.z, make_float4(sx, sy, sz, 0.0f));
             const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)s;
             bool hit = active && d2 < r2;
-            if (hit) hit = key <= key_last[__float_as_int(c.w)];
+            hit = hit && key <= key_last[hit ? __float_as_int(c.w) : 0];          // unconditional gather
             const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const int pos = cnt + lane_rank(m);
-                if (pos < GRID_SLAB) slab[pos] = c;
-            }
+            const int pos = cnt + lane_rank(m);
+            slab[(hit && pos < GRID_SLAB) ? pos : GRID_SLAB + lane] = c;      // branch free (dummy slot per lane)
             cnt += __builtin_popcountll(m);
         };
         if (gr.s_len > 0) {
@@ -798,8 +799,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
                 const int p = rb[r] + lane;
-                c[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < re[r]) c[r] = sorted[p];
+                c[r] = sorted[p < re[r] ? p : 0];          // unconditional, masked by `active`
             }
 #pragma unroll
             for (int r = 0; r < 9; ++r) {

@@ -266,26 +266,33 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
                                                           unsigned long long* __restrict__ key_last)
 {
     constexpr int CAP = 128;
-    __shared__ unsigned long long slab_all[4][CAP];
+    __shared__ unsigned long long slab_all[4][CAP + 64];      // + one dummy slot per lane (unconditional writes)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     unsigned long long* slab = slab_all[wave];
     int local_max = 0;
     int64_t ibeg, iend;
     ws_block_range(nq, ibeg, iend);
+    // queries come cloud by cloud (stacked order, and the cell order of self-queries follows the clouds'
+    // cell ranges), so the element index only ever advances: keep it and its grid in registers
+    int b = 0;
+    CloudGrid g = grids[0];
     for (int64_t it = ibeg + wave; it < iend; it += 4) {
         const int64_t q = qorder ? (int64_t)qorder[it] : it;
-        const int b = find_cloud_q(grids, nb, q);
-        const CloudGrid g = grids[b];
+        if (q < g.q_base || q >= g.q_base + g.q_len) {
+            b = find_cloud_q(grids, nb, q);
+            g = grids[b];
+        }
         const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
         int cnt = 0;
         auto take = [&](const float4& c, bool active) {
             const float d2 = ref_d2(qx, qy, qz, c);
             const bool hit = active && d2 < r2;
             const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const int pos = cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                if (pos < CAP) slab[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c.w);
-            }
+            // branch free: misses and overflow land in the lane's dummy slot (exec-mask branches cost the
+            // scalar unit more than the store costs the LDS)
+            const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            slab[(hit && pos < CAP) ? pos : CAP + lane] =
+                ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c.w);
             cnt += __builtin_popcountll(m);
         };
         if (g.s_len > 0) {
@@ -306,8 +313,7 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
                 const int p = rb[r] + lane;
-                c[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < re[r]) c[r] = sorted[p];
+                c[r] = sorted[p < re[r] ? p : 0];          // unconditional (entry 0 exists: s_len > 0), masked by `active`
             }
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
