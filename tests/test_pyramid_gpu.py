@@ -154,16 +154,22 @@ def test_grid_backward_matches_transposed_table():
         kp = torch.from_numpy(load_kernels(r * cfg.KP_extent / cfg.conv_radius * 1.0, 15, dimension=3, fixed="center")
                               .astype(np.float32)).to(dev) if False else torch.randn(15, 3, device=dev) * (0.6 * r)
         extent = r * cfg.KP_extent / cfg.conv_radius
-        for ci in (32, 3):
+        for ci, variant in ((32, "rigid"), (3, "rigid"), (16, "deformable"), (64, "gaussian-closest")):
             x = torch.randn(p.shape[0], ci, device=dev)
+            kw = {}
+            if variant == "deformable":       # per-query kernel points + modulations (blocks.py:262-276, 366-367)
+                kw = dict(deformed_kp=kp[None] + 0.1 * r * torch.randn(p.shape[0], 15, 3, device=dev),
+                          modulations=torch.rand(p.shape[0], 15, device=dev), want_min_d2=True)
+            elif variant == "gaussian-closest":
+                kw = dict(influence="gaussian", aggregation="closest")
             outs = []
             for use_grid in (True, False):
                 ops.GRID_BACKWARD = use_grid
                 ops.clear_table_cache()
                 xx = x.clone().requires_grad_(True)
-                wf, _ = ops.kpconv_gather(xx, p, p, inds, kp, extent)
+                wf, _ = ops.kpconv_gather(xx, p, p, inds, kp, extent, **kw)
                 wf.backward(torch.ones_like(wf) * 0.5 + wf.detach() * 0.1)
                 outs.append(xx.grad.clone())
             ops.GRID_BACKWARD = True
             assert int(grid.overflow.item()) == 0
-            assert torch.equal(outs[0], outs[1]), (l, ci, float((outs[0] - outs[1]).abs().max()))
+            assert torch.equal(outs[0], outs[1]), (l, ci, variant, float((outs[0] - outs[1]).abs().max()))
