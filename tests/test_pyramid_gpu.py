@@ -221,3 +221,81 @@ def test_training_converges_on_synthetic_spheres():
     losses = torch.stack(losses).cpu().numpy()
     assert np.isfinite(losses).all()
     assert losses[-5:].mean() < 0.5 * losses[:3].mean(), losses
+
+
+@pytest.mark.gpu
+def test_kpfcnn_mprm_vs_golden():
+    """weak-label network (attention blocks, class logits, CAMs, both losses, gradients) against the reference's own
+    KPFCNN_mprm run on CPU (tests/golden/make_golden_mprm.py): 1e-4 relative per tensor, 1e-3 on parameter gradients"""
+    import numpy as np
+    from weasal_amd import config as wcfg
+    from weasal_amd.architectures import KPFCNN_mprm
+    from weasal_amd.pyramid import PyramidBatch
+    g = golden("g10_mprm.npz")
+    dev = torch.device("cuda:0")
+
+    class Cfg(wcfg.Config):
+        dataset = "GoldenWL"
+        num_classes = 6
+        architecture = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb',
+                        'nearest_upsample', 'nearest_upsample']
+        num_kernel_points = 15
+        first_subsampling_dl = 0.3
+        conv_radius = 2.5
+        deform_radius = 1.0
+        KP_extent = 1.0
+        KP_influence = 'linear'
+        aggregation_mode = 'sum'
+        first_features_dim = 16
+        in_features_dim = 4
+        modulated = False
+        use_batch_norm = True
+        batch_norm_momentum = 0.02
+        deform_fitting_mode = 'point2point'
+        deform_fitting_power = 1.0
+        deform_lr_factor = 0.1
+        repulse_extent = 1.2
+        class_w = []
+    cfg = Cfg()
+    L = 3
+    li = [torch.from_numpy(g["points_%d" % l]).to(dev) for l in range(L)]
+    li += [torch.from_numpy(g["neighbors_%d" % l].astype(np.int64)).to(dev) for l in range(L)]
+    li += [torch.from_numpy(g["pools_%d" % l].astype(np.int64)).to(dev) for l in range(L)]
+    li += [torch.from_numpy(g["upsamples_%d" % l].astype(np.int64)).to(dev) for l in range(L)]
+    li += [torch.from_numpy(g["lengths_%d" % l].astype(np.int32)).to(dev) for l in range(L)]
+    li += [torch.from_numpy(g["features"]).to(dev), torch.from_numpy(g["labels"]).to(dev)]
+    batch = PyramidBatch(li)
+    batch.center_pts = torch.from_numpy(g["center_pts"]).to(dev)
+    np.random.seed(0); torch.manual_seed(0)
+    net = KPFCNN_mprm(cfg, np.arange(6), []).to(dev).train()
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd0/")}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all("num_batches_tracked" in m for m in missing), (missing, unexpected)
+
+    x, cla, cam = net(batch, cfg)
+
+    def close(a, ref, tol, what):
+        ref = torch.from_numpy(np.asarray(ref)).to(a.device)
+        err = float((a.detach() - ref).abs().max()); scale = float(ref.abs().max())
+        assert err <= tol * max(scale, 1e-6), (what, err, scale)
+    close(x, g["x"], 1e-4, "x")
+    for i in range(4):
+        close(cla[i], g["cla_logits_%d" % i], 1e-4, "cla %d" % i)
+        close(cam[i], g["cam_%d" % i], 1e-4, "cam %d" % i)
+    loss_cls = net.class_logits_loss(cla, torch.from_numpy(g["cloud_lb"]).to(dev))
+    sizes = g["region_sizes"]; flat = g["regions_flat"]
+    regions = [[flat[:sizes[0]], flat[sizes[0]:sizes[0] + sizes[1]]], []]
+    regions_lb = [[g["regions_lb"][0], g["regions_lb"][1]], []]
+    loss_reg = net.region_mprm_loss(cam, regions, regions_lb, batch.lengths[0].cpu())
+    assert abs(float(loss_cls.detach()) - float(g["loss_cls"])) <= 1e-4 * abs(float(g["loss_cls"]))
+    assert abs(float(loss_reg.detach()) - float(g["loss_reg"])) <= 1e-4 * abs(float(g["loss_reg"]))
+    assert abs(net.accuracy(x, batch.labels) - float(g["acc"])) < 1e-6
+    (loss_cls + loss_reg).backward()
+    grads = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(grads.keys()) == names
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        got = float(grads[n].double().norm())
+        assert abs(got - float(ref_norm)) <= 1e-3 * max(float(ref_norm), 1e-8), (n, got, float(ref_norm))
+        if ("grad/" + n) in g.files:
+            close(grads[n], g["grad/" + n], 1e-3, "grad " + n)

@@ -6,8 +6,8 @@ keep the reference's names, wiring and state_dict keys (models/architectures.py:
 underneath is a HIP kernel (weasal_amd/blocks.py).  ``p2p_fitting_regularizer`` follows
 architectures.py:24-57.  ``contrast_loss`` (architectures.py:405-504) is restated without torch_scatter and
 without ``.cuda()`` calls (**parity unpinned**: torch_scatter is absent, so the
-reference function has never run here -- it is checked against oracle/contrast_ref.py only).  Not provided: the
-weak-label ``KPFCNN_mprm`` (rank 3).
+reference function has never run here -- it is checked against oracle/contrast_ref.py only).  The weak-label
+``KPFCNN_mprm`` (architectures.py:507-807, rank 3) is at the end of this file, pinned by golden g10.
 """
 import numpy as np
 import torch
@@ -239,4 +239,167 @@ class KPFCNN(nn.Module):
     def accuracy(self, outputs, labels):
         target = self._targets(labels)
         predicted = torch.argmax(outputs.data, dim=1)
+        return (predicted == target).sum().item() / target.size(0)
+
+
+class KPFCNN_mprm(nn.Module):
+    """KP-FCNN for weak labels with multi-path region mining and the elevation attention head
+    (models/architectures.py:507-807): encoder as in KPFCNN, then `ele_att`,
+    `multi_path_att` (no / point-wise / spatial / channel attention, each projected to the classes), per-sphere
+    class logits of every path and the shared parameter-free decoder (nearest upsampling) that turns the four
+    class-activation maps into point-wise scores; `x` is their element-wise maximum.  Same constructor, module
+    names (state_dict keys), return values and loss methods as the reference; no `.cuda()` anywhere -- tensors
+    stay on the device of the batch.  Pinned by tests/golden/g10_mprm.npz, generated with the reference's classes."""
+
+    def __init__(self, config, lbl_values, ign_lbls):
+        super(KPFCNN_mprm, self).__init__()
+        from .blocks import ele_att, global_average_block, multi_path_att
+        arch = list(config.architecture)
+        layer = 0
+        r = config.first_subsampling_dl * config.conv_radius
+        in_dim = config.in_features_dim
+        out_dim = config.first_features_dim
+        self.K = config.num_kernel_points
+        self.C = len(lbl_values) - len(ign_lbls)
+        self.features_layer = 'encoder_blocks.5.unary_shortcut.mlp'
+        self.forward_features = {}
+        self.backward_features = {}
+
+        self.encoder_blocks = nn.ModuleList()
+        self.encoder_skip_dims = []
+        self.encoder_skips = []
+        for block_i, block in enumerate(arch):
+            if 'equivariant' in block and out_dim % 3 != 0:
+                raise ValueError('Equivariant block but features dimension is not a factor of 3')
+            if any(tag in block for tag in _LAYER_CHANGE + ('attention',)):
+                self.encoder_skips.append(block_i)
+                self.encoder_skip_dims.append(in_dim)
+            if 'attention' in block or 'upsample' in block:
+                break
+            self.encoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim // 2 if 'simple' in block else out_dim
+            if 'pool' in block or 'strided' in block:
+                layer += 1
+                r *= 2
+                out_dim *= 2
+
+        nc = config.num_classes
+        self.multi_att = multi_path_att('attention', out_dim, out_dim, r, layer, config)
+        self.ele_head = ele_att('ele_attention', 2, out_dim, r, layer, config)
+        self.no_ga = global_average_block('ga1', nc, nc, layer, config)
+        self.da_ga = global_average_block('ga2', nc, nc, layer, config)
+        self.spa_ga = global_average_block('ga3', nc, nc, layer, config)
+        self.cha_ga = global_average_block('ga4', nc, nc, layer, config)
+
+        self.decoder_blocks = nn.ModuleList()
+        self.decoder_concats = []
+        start_i = next((i for i, b in enumerate(arch) if 'upsample' in b), 0)
+        for block_i, block in enumerate(arch[start_i:]):
+            if block_i > 0 and 'upsample' in arch[start_i + block_i - 1]:
+                in_dim += self.encoder_skip_dims[layer]
+                self.decoder_concats.append(block_i)
+            self.decoder_blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+            in_dim = out_dim
+            if 'upsample' in block:
+                layer -= 1
+                r *= 0.5
+                out_dim = out_dim // 2
+
+        self.valid_labels = np.sort([c for c in lbl_values if c not in ign_lbls])
+        if len(config.class_w) > 0:
+            class_w = torch.from_numpy(np.array(config.class_w, dtype=np.float32))
+            self.criterion = torch.nn.CrossEntropyLoss(weight=class_w, ignore_index=-1)
+            self.criterion_multi = torch.nn.BCEWithLogitsLoss(weight=class_w)
+        else:
+            self.criterion = torch.nn.CrossEntropyLoss(ignore_index=-1)
+            self.criterion_multi = torch.nn.BCEWithLogitsLoss()
+        self.deform_fitting_mode = config.deform_fitting_mode
+        self.deform_fitting_power = config.deform_fitting_power
+        self.deform_lr_factor = config.deform_lr_factor
+        self.repulse_extent = config.repulse_extent
+        self.output_loss = 0
+        self.reg_loss = 0
+        self.l1 = nn.L1Loss()
+        self.register_hooks()
+
+    def register_hooks(self):
+        """keep the output (and its gradient) of `features_layer` per device, as the reference does for its
+        class-activation visualisations (architectures.py:651-665)"""
+        def forward_hook(_module, _inp, out):
+            self.forward_features[out.device] = out
+
+        def backward_hook(_module, _grad_in, grad_out):
+            self.backward_features[grad_out[0].device] = grad_out[0]
+        for name, module in self.named_modules():
+            if name == self.features_layer:
+                module.register_forward_hook(forward_hook)
+                module.register_full_backward_hook(backward_hook)
+
+    def forward(self, batch, config):
+        if hasattr(batch, "activate"):
+            batch.activate()
+        else:
+            ops.clear_table_cache()
+        x = batch.features.clone().detach()
+        ele_down = batch.points[2][:, -1].unsqueeze(-1).clone().detach()     # heights at the attention level (:672)
+        for block_i, block_op in enumerate(self.encoder_blocks):
+            x = block_op(x, batch)
+        x = self.ele_head(x, ele_down, batch)
+        spa_att, cha_att, no_att, poi_att = self.multi_att(x, batch)
+        cla_logits = [self.no_ga(no_att, batch), self.da_ga(poi_att, batch), self.spa_ga(spa_att, batch),
+                      self.cha_ga(cha_att, batch)]
+        for block_op in self.decoder_blocks:
+            no_att = block_op(no_att, batch)
+            poi_att = block_op(poi_att, batch)
+            spa_att = block_op(spa_att, batch)
+            cha_att = block_op(cha_att, batch)
+        x = torch.max(torch.max(torch.max(no_att, poi_att), spa_att), cha_att)
+        return x, cla_logits, [no_att, poi_att, spa_att, cha_att]
+
+    def class_logits_loss(self, class_logits, cloud_lb):
+        """BCE-with-logits of the four per-sphere class logits against one weak label vector per sphere, plus the
+        deformable regulariser (architectures.py:709-733)"""
+        self.output_loss1 = self.criterion_multi(class_logits[0], cloud_lb)
+        self.output_loss2 = self.criterion_multi(class_logits[1], cloud_lb)
+        self.output_loss3 = self.criterion_multi(class_logits[2], cloud_lb)
+        self.output_loss4 = self.criterion_multi(class_logits[3], cloud_lb)
+        if self.deform_fitting_mode == 'point2point':
+            self.reg_loss = p2p_fitting_regularizer(self)
+        elif self.deform_fitting_mode == 'point2plane':
+            raise ValueError('point2plane fitting mode not implemented yet.')
+        else:
+            raise ValueError('Unknown fitting mode: ' + self.deform_fitting_mode)
+        return self.output_loss1 + self.output_loss2 + self.output_loss3 + self.output_loss4 + self.reg_loss
+
+    def region_mprm_loss(self, cam, regions_all, regions_lb, batch_lengths):
+        """overlap-region loss (architectures.py:735-784): the four class-activation maps are averaged over every
+        labelled sub-region of every sphere and compared with the sub-region's weak labels"""
+        dev = cam[0].device
+        cam_all = torch.stack(cam, dim=0)
+        averaged, all_lbs = [], []
+        start = 0
+        for ri in range(len(regions_all)):
+            n = int(batch_lengths[ri])
+            if len(regions_all[ri]) > 0:
+                logits = cam_all[:, start:start + n, :]
+                all_lbs.append(np.stack(regions_lb[ri]).astype('float32'))
+                for region in regions_all[ri]:
+                    idx = torch.from_numpy(np.asarray(region).astype('int64')).to(dev)
+                    assert logits.shape[1] >= int(idx.max()), 'logits problem'
+                    averaged.append(torch.mean(logits[:, idx, :], dim=1))
+            start += n
+        all_lbs = torch.from_numpy(np.vstack(all_lbs)).to(dev)
+        averaged = torch.stack(averaged)
+        self.output_loss = 0
+        for ii in range(averaged.shape[1]):
+            self.output_loss = self.output_loss + self.criterion_multi(averaged[:, ii, :], all_lbs)
+        return self.output_loss
+
+    def accuracy(self, logits, labels):
+        if not len(logits.size()) == 2:
+            raise ValueError('Wrong logits output dimension: Expected 2, got ' + str(len(logits.size())))
+        target = -torch.ones_like(labels)
+        for i, c in enumerate(self.valid_labels):
+            target[labels == c] = i
+        predicted = torch.argmax(logits, dim=1)
         return (predicted == target).sum().item() / target.size(0)

@@ -358,3 +358,163 @@ class MaxPoolBlock(nn.Module):
 
     def forward(self, x, batch):
         return max_pool(x, batch.pools[self.layer_ind + 1])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Attention blocks of the weak-label network KPFCNN_mprm (models/blocks.py:758-1011; SURVEY.md section 8f rank 3).
+# Per input sphere a dense softmax attention (points x points, or channels x channels) built from UnaryBlock
+# projections; same module names / state_dict keys as the reference.  Device agnostic: the reference's `.cuda()`
+# calls on fresh tensors (blocks.py:796,863,989) are replaced by "same device as the features", and its repeated
+# torch.cat inside the per-sphere loop by one cat at the end (same values).
+# ----------------------------------------------------------------------------------------------------------------------
+def _per_cloud(lengths):
+    """[(start, end)] of the stacked spheres; `lengths` is the host or device length vector of the layer"""
+    ls = [int(v) for v in (lengths.tolist() if hasattr(lengths, "tolist") else lengths)]
+    out, s = [], 0
+    for n in ls:
+        out.append((s, s + n))
+        s += n
+    return out
+
+
+class spatial_att(nn.Module):
+    """point-to-point attention inside each sphere (blocks.py:758-822): merged = simple2(gamma * softmax(QK^T)V + f),
+    and the attention output divided by the sphere's point count (input of the point-wise path)"""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(spatial_att, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.simple1 = SimpleBlock2(block_name, in_dim, out_dim, radius, layer_ind, config)
+        self.unary1 = UnaryBlock(out_dim, out_dim // 8, self.use_bn, self.bn_momentum)
+        self.unary2 = UnaryBlock(out_dim, out_dim // 8, self.use_bn, self.bn_momentum)
+        self.unary3 = UnaryBlock(out_dim, out_dim, self.use_bn, self.bn_momentum)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.softmax = nn.Softmax(dim=-1)
+        self.simple2 = SimpleBlock2(block_name, in_dim, out_dim, radius, layer_ind, config)
+
+    def forward(self, features, batch):
+        features = self.simple1(features, batch)
+        q, k, v = self.unary1(features), self.unary2(features), self.unary3(features)
+        outs, outs_n = [], []
+        for a, b in _per_cloud(batch.lengths[self.layer_ind]):
+            att = torch.matmul(self.softmax(torch.matmul(q[a:b], k[a:b].T)), v[a:b])
+            outs.append(att)
+            outs_n.append(att / float(b - a))
+        x = torch.cat(outs, 0) if outs else features.new_zeros((0, features.shape[1]))
+        xn = torch.cat(outs_n, 0) if outs_n else features.new_zeros((0, features.shape[1]))
+        merged = self.simple2(self.gamma * x + features, batch)
+        return merged, xn
+
+
+class channel_att(nn.Module):
+    """channel-to-channel attention inside each sphere (blocks.py:824-883)"""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(channel_att, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.simple1 = SimpleBlock2(block_name, in_dim, out_dim // 8, radius, layer_ind, config)
+        self.unary1 = UnaryBlock(out_dim // 8, out_dim // 8, self.use_bn, self.bn_momentum)
+        self.unary2 = UnaryBlock(out_dim // 8, out_dim // 8, self.use_bn, self.bn_momentum)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.softmax = nn.Softmax(dim=-1)
+        self.simple2 = SimpleBlock2(block_name, out_dim // 8, out_dim, radius, layer_ind, config)
+
+    def forward(self, features, batch):
+        features = self.simple1(features, batch)
+        x1, x2 = self.unary1(features), self.unary2(features)
+        outs = []
+        for a, b in _per_cloud(batch.lengths[self.layer_ind]):
+            energy = torch.matmul(x1[a:b].T, x2[a:b])
+            energy_new = torch.max(energy, -1, keepdim=True)[0].expand_as(energy) - energy
+            outs.append(torch.matmul(features[a:b], self.softmax(energy_new)))
+        x = torch.cat(outs, 0) if outs else features.new_zeros((0, features.shape[1]))
+        return self.simple2(self.gamma * x + features, batch)
+
+
+class multi_path_att(nn.Module):
+    """no-attention, spatial, channel and point-wise paths, each projected to the classes (blocks.py:885-928)"""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(multi_path_att, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        fdim = config.num_classes
+        self.sa_f = spatial_att(block_name, in_dim, out_dim, radius, layer_ind, config)
+        self.ca_f = channel_att(block_name, in_dim, out_dim, radius, layer_ind, config)
+        self.simple1 = SimpleBlock2(block_name, in_dim + out_dim, out_dim, radius, layer_ind, config)
+        self.sa_unary = UnaryBlock(out_dim, fdim, self.use_bn, self.bn_momentum)
+        self.ca_unary = UnaryBlock(out_dim, fdim, self.use_bn, self.bn_momentum)
+        self.no_unary = UnaryBlock(in_dim, fdim, self.use_bn, self.bn_momentum)
+        self.pa_unary = UnaryBlock(out_dim, fdim, self.use_bn, self.bn_momentum)
+
+    def forward(self, features, batch):
+        sa, sa_x = self.sa_f(features, batch)
+        ca = self.ca_f(features, batch)
+        pa = self.simple1(torch.cat((features, sa_x), dim=1), batch)
+        return (self.sa_unary(sa, batch), self.ca_unary(ca, batch), self.no_unary(features, batch),
+                self.pa_unary(pa, batch))
+
+
+class global_average_block(nn.Module):
+    """per-sphere mean of the features (blocks.py:930-955)"""
+
+    def __init__(self, block_name, in_dim, out_dim, layer_ind, config):
+        super(global_average_block, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+
+    def forward(self, features, batch):
+        return global_average(features, batch.lengths[self.layer_ind])
+
+
+class ele_att(nn.Module):
+    """elevation attention (blocks.py:957-1011): channel attention whose queries / keys come from the height of
+    the points (relative and absolute: h, h + centre height of the sphere)"""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(ele_att, self).__init__()
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.unary1 = UnaryBlock(in_dim, out_dim, self.use_bn, self.bn_momentum)
+        self.unary2 = UnaryBlock(in_dim, out_dim, self.use_bn, self.bn_momentum)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.softmax = nn.Softmax(dim=-1)
+        self.simple2 = SimpleBlock2(block_name, out_dim, out_dim, radius, layer_ind, config)
+
+    def forward(self, features, h, batch):
+        # the two projections run once on all spheres (UnaryBlock is row-wise, so this equals the per-sphere calls)
+        spans = _per_cloud(batch.lengths[self.layer_ind])
+        if h.shape[0] > 0:
+            centre_z = torch.cat([batch.center_pts[ii][-1].to(h.dtype).expand(b - a, 1) for ii, (a, b) in enumerate(spans)], 0)
+        else:
+            centre_z = h
+        ele_f = torch.cat((h, h + centre_z), dim=1)
+        query, key = self.unary1(ele_f), self.unary2(ele_f)
+        outs = []
+        for a, b in spans:
+            att = self.softmax(torch.matmul(query[a:b].T, key[a:b]))
+            outs.append(torch.matmul(features[a:b], att))
+        x = torch.cat(outs, 0) if outs else features.new_zeros((0, features.shape[1]))
+        return self.simple2(self.gamma * x + features, batch)
