@@ -154,3 +154,54 @@ def test_kpfcnn_vs_golden_cpu():
     for k in g8.files:
         if k.startswith("sd1/"):
             assert rel(sd1[k[4:]].numpy(), g8[k]) < 1e-4, k
+
+
+def test_kpfcnn_mprm_vs_golden_cpu():
+    """G10: the weak-label network (attention blocks, class logits, CAMs, both losses, gradient norms) of the
+    reference, reproduced by weasal_amd.architectures.KPFCNN_mprm on the CPU through the restatement -- the host
+    logic and module wiring, without the HIP operators (those are checked by the GPU twin of this test)."""
+    from weasal_amd.architectures import KPFCNN_mprm
+    from weasal_amd.config import Config
+    g = golden("g10_mprm.npz")
+
+    class Cfg(Config):
+        num_classes = 6
+        architecture = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb',
+                        'nearest_upsample', 'nearest_upsample']
+        first_subsampling_dl = 0.3
+        deform_radius = 1.0
+        first_features_dim = 16
+        in_features_dim = 4
+        batch_norm_momentum = 0.02
+        repulse_extent = 1.2
+        saving = False
+    cfg = Cfg()
+    np.random.seed(0)
+    net = KPFCNN_mprm(cfg, np.arange(6), [])
+    sd = {k[4:]: t(g[k]) for k in g.files if k.startswith("sd0/")}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all("num_batches_tracked" in m for m in missing), (missing, unexpected)
+    net.train()
+    b = types.SimpleNamespace()
+    b.points = [t(g["points_%d" % l]) for l in range(3)]
+    b.neighbors = [t(g["neighbors_%d" % l]) for l in range(3)]
+    b.pools = [t(g["pools_%d" % l]) for l in range(3)]
+    b.upsamples = [t(g["upsamples_%d" % l]) for l in range(3)]
+    b.lengths = [t(g["lengths_%d" % l]) for l in range(3)]
+    b.features, b.labels, b.center_pts = t(g["features"]), t(g["labels"]), t(g["center_pts"])
+    with kpconv_ref.cpu_reference_mode():
+        x, cla, cam = net(b, cfg)
+        loss_cls = net.class_logits_loss(cla, t(g["cloud_lb"]))
+        sizes, flat = g["region_sizes"], g["regions_flat"]
+        regions = [[flat[:sizes[0]], flat[sizes[0]:sizes[0] + sizes[1]]], []]
+        loss_reg = net.region_mprm_loss(cam, regions, [[g["regions_lb"][0], g["regions_lb"][1]], []], b.lengths[0])
+        (loss_cls + loss_reg).backward()
+    assert rel(x.detach().numpy(), g["x"]) < 1e-4
+    for i in range(4):
+        assert rel(cla[i].detach().numpy(), g["cla_logits_%d" % i]) < 1e-4
+        assert rel(cam[i].detach().numpy(), g["cam_%d" % i]) < 1e-4
+    assert abs(loss_cls.item() - float(g["loss_cls"])) < 1e-5 and abs(loss_reg.item() - float(g["loss_reg"])) < 1e-5
+    grads = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+    assert sorted(grads) == [str(n) for n in g["grad_names"]]
+    for n, ref_norm in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(float(grads[str(n)].double().norm()) - float(ref_norm)) <= 1e-3 * max(float(ref_norm), 1e-8), n
