@@ -299,3 +299,30 @@ def test_kpfcnn_mprm_vs_golden():
         assert abs(got - float(ref_norm)) <= 1e-3 * max(float(ref_norm), 1e-8), (n, got, float(ref_norm))
         if ("grad/" + n) in g.files:
             close(grads[n], g["grad/" + n], 1e-3, "grad " + n)
+
+
+@pytest.mark.gpu
+def test_grid_backward_pair_conservation_full_size():
+    """BASELINE config 3 size (8 x 50 000 points): with constant influence and unit inputs the table-free backward
+    must return, for every support, 15 x (number of rows that contain it) -- a size-independent property that
+    checks the membership test against the index matrix itself, on every level that has a grid"""
+    import numpy as np
+    from weasal_amd import config as wcfg, ops, pyramid, synthetic
+    dev = torch.device("cuda:0")
+    cfg = wcfg.DALESPLConfig()
+    wl = synthetic.WORKLOADS["dales"]
+    pts, feats, labels, lens = synthetic.make_inputs(11, wl["spheres"], wl["points"], wl["radius"], cfg.in_features_dim)
+    pts, feats, labels = (torch.from_numpy(a).to(dev) for a in (pts, feats, labels))
+    batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
+    batch.activate()
+    assert len(batch.search_grids) >= 4
+    for l, (inds, grid) in enumerate(batch.search_grids):
+        p = batch.points[l]
+        ns = p.shape[0]
+        indeg = torch.bincount(inds[inds < ns].flatten(), minlength=ns)
+        x = torch.ones(ns, 1, device=dev, requires_grad=True)
+        wf, _ = ops.kpconv_gather(x, p, p, inds, torch.zeros(15, 3, device=dev), 1.0, influence="constant")
+        wf.backward(torch.ones_like(wf))
+        got = torch.round(x.grad[:, 0].double() / 15).long()
+        assert int(grid.overflow.item()) == 0
+        assert torch.equal(got, indeg), (l, int((got != indeg).sum()))
