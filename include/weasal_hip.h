@@ -230,6 +230,11 @@ const int32_t* ws_radius_neighbors_counts(const ws_neighbors_ws* ws);
  *                                     in-degree of a support with more than 192 incoming pairs (result then invalid);
  *                                     impossible when the search reported max_count <= 128 for that matrix. */
 int ws_radius_neighbors_set_key_last(ws_neighbors_ws* ws, uint64_t* d_key_last);
+/* one-shot hint: the NEXT plan / search uses the same supports (pointer, lengths, radius AND unchanged contents -- the
+ * caller vouches) as the previous one and keeps its cell grid; ignored when anything checkable differs.  In the pyramid
+ * of datasets/common.py:487-545 the conv, pool and (previous level's) upsample searches share one support set and one
+ * radius per level: 5 grids instead of 13. */
+int ws_radius_neighbors_reuse_grid(ws_neighbors_ws* ws, int32_t on);
 int ws_radius_neighbors_grid_info(const ws_neighbors_ws* ws, int32_t* nb, int64_t* cells, int64_t* ns, int64_t* blob_bytes);
 int ws_radius_neighbors_grid_export(const ws_neighbors_ws* ws, void* blob, void* stream);
 int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,

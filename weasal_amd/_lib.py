@@ -42,6 +42,7 @@ SIGNATURES = {
     "ws_contrast_rows_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp]),
     "ws_radius_neighbors_set_key_last": (C.c_int, [_vp, _vp]),
+    "ws_radius_neighbors_reuse_grid": (C.c_int, [_vp, _i32]),
     "ws_radius_neighbors_grid_info": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ws_radius_neighbors_grid_export": (C.c_int, [_vp, _vp, _vp]),
     "ws_kpconv_gather_bwd_x_grid": (C.c_int, [_vp, _i64, _vp, _i32, _i64, _vp, C.c_float, _vp, _i32, _vp, _i32, _vp, _vp,

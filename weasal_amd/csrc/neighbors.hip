@@ -16,6 +16,7 @@
 #include "ws_scan.h"
 #include "ws_grid.h"
 #include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -57,6 +58,14 @@ __global__ void nb_upload_kernel(GridTable t, int nb, CloudGrid* __restrict__ ds
 {
     const int b = threadIdx.x;
     if (b < nb) dst[b] = t.g[b];
+}
+
+// grid reuse: only the query ranges of the per-element table change
+struct QueryTable { int q_base[GRID_TABLE_MAX]; int q_len[GRID_TABLE_MAX]; };
+__global__ void nb_update_queries_kernel(QueryTable t, int nb, CloudGrid* __restrict__ grids)
+{
+    const int b = threadIdx.x;
+    if (b < nb) { grids[b].q_base = t.q_base[b]; grids[b].q_len = t.q_len[b]; }
 }
 
 __global__ void nb_grid_setup_kernel(CloudGrid* __restrict__ grids, const float* __restrict__ bbox, int nb, float radius)
@@ -410,6 +419,10 @@ struct ws_neighbors_ws {
     int64_t cells = 0;                         // cells of the last plan (all elements)
     int32_t* max_count_word = nullptr;         // device word holding the maximum row length of the current plan
     unsigned long long* key_last = nullptr;    // one-shot output of the next fill (ws_radius_neighbors_set_key_last)
+    bool reuse_next = false;                   // one-shot: the next plan keeps the support grid (ws_radius_neighbors_reuse_grid)
+    const float* supports = nullptr;           // supports of the current grid
+    float radius = 0.f;
+    std::vector<int32_t> s_lens;               // per-element support counts of the current grid
 };
 
 extern "C" {
@@ -439,6 +452,31 @@ static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, con
     WS_REQUIRE(nb >= 1 && nq >= 0 && ns >= 0, "bad sizes nb=%d nq=%lld ns=%lld", nb, (long long)nq, (long long)ns);
     WS_REQUIRE(ns < (1ll << 30) && nq < (1ll << 31), "point count exceeds int32 range");
     ws->max_count_host = 0;
+    const bool reuse = ws->reuse_next;
+    ws->reuse_next = false;
+    if (reuse && ws->supports == supports && ws->ns == ns && ws->nb == nb && ws->radius == radius && nb <= GRID_TABLE_MAX &&
+        ws->max_count_word && nq > 0 && (int)ws->s_lens.size() == nb &&
+        std::equal(ws->s_lens.begin(), ws->s_lens.end(), h_s_lens)) {
+        // same supports, same radius as the previous plan (the caller vouches that the support DATA is unchanged):
+        // bounding boxes, bins and the cell-sorted copy stay; only the query ranges and the counters are new
+        QueryTable qt;
+        int64_t qsum = 0;
+        for (int b = 0; b < nb; ++b) {
+            WS_REQUIRE(h_q_lens[b] >= 0, "negative batch length");
+            qt.q_base[b] = (int)qsum; qt.q_len[b] = h_q_lens[b];
+            qsum += h_q_lens[b];
+        }
+        WS_REQUIRE(qsum == nq, "batch lengths do not sum to the query count (%lld/%lld)", (long long)qsum, (long long)nq);
+        WS_REQUIRE(queries, "NULL argument");
+        int rc2;
+        if ((rc2 = ws->counts.ensure((size_t)nq))) return rc2;
+        nb_update_queries_kernel<<<1, 64, 0, st>>>(qt, nb, ws->grids.p);
+        WS_LAUNCH_CHECK();
+        WS_HIP(hipMemsetAsync(ws->max_count_word, 0, sizeof(int32_t), st));
+        ws->self_query = (queries == supports && nq == ns);
+        ws->queries = queries; ws->nq = nq;
+        return WS_OK;
+    }
     ws->nq = 0;
     std::vector<CloudGrid> hg((size_t)nb);
     int64_t qsum = 0, ssum = 0, cells = 0;
@@ -497,6 +535,8 @@ static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, con
     WS_LAUNCH_CHECK();
     ws->self_query = (queries == supports && nq == ns);
     ws->queries = queries; ws->nq = nq; ws->ns = ns; ws->nb = nb; ws->cells = cells;
+    ws->supports = supports; ws->radius = radius;
+    ws->s_lens.assign(h_s_lens, h_s_lens + nb);
     ws->r2 = radius * radius;   // neighbors.cpp:226
     return WS_OK;
 }
@@ -624,6 +664,13 @@ int ws_radius_neighbors_order(const ws_neighbors_ws* ws, int32_t* out_order, voi
 }
 
 const int32_t* ws_radius_neighbors_counts(const ws_neighbors_ws* ws) { return ws ? ws->counts.p : nullptr; }
+
+int ws_radius_neighbors_reuse_grid(ws_neighbors_ws* ws, int32_t on)
+{
+    WS_REQUIRE(ws, "NULL argument");
+    ws->reuse_next = on != 0;
+    return WS_OK;
+}
 
 int ws_radius_neighbors_set_key_last(ws_neighbors_ws* ws, uint64_t* d_key_last)
 {

@@ -591,7 +591,7 @@ class DeferredSearches:
         self.slots = torch.zeros(capacity, dtype=torch.int32, device=device)
         self.calls = []
 
-    def add(self, queries, supports, q_lens, s_lens, radius, limit, want_order=False, want_grid=False):
+    def add(self, queries, supports, q_lens, s_lens, radius, limit, want_order=False, want_grid=False, reuse_grid=False):
         """-> index matrix; with want_order / want_grid: (matrix, cell order or None, SearchGrid or None).
         The grid is only meaningful for a self-query (queries is supports) and while `counts()` of this call
         stays <= 128 (checked by the caller after finish())."""
@@ -609,6 +609,8 @@ class DeferredSearches:
         slot = len(self.calls)
         grid = None
         with torch.cuda.device(q.device):
+            if reuse_grid:      # same supports (tensor, lengths, radius, contents) as the previous search of this workspace
+                check(lib.ws_radius_neighbors_reuse_grid(ws, 1))
             if want_grid:
                 grid = SearchGrid()
                 grid.key_last = torch.empty((q.shape[0],), dtype=torch.int64, device=q.device)

@@ -60,7 +60,11 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
     slots = []   # (list, position) of every deferred matrix
     pending_grids = []   # (slot index, SearchGrid) of the self-query searches (table-free KPConv backward)
 
+    last = {"s": None, "r": None}     # supports / radius of the previous deferred search (grid reuse)
+
     def search(q, s, ql, sl, r, layer, register_order=False):
+        reuse = deferred is not None and last["s"] is s and last["r"] == float(np.float32(r))
+        last["s"], last["r"] = s, float(np.float32(r))
         if deferred is None:
             if not register_order:
                 return ops.radius_neighbors(q, s, ql, sl, r, dtype=torch.int64)
@@ -69,13 +73,13 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
             return inds
         if register_order:
             want_grid = search_grids is not None and q is s
-            res = deferred.add(q, s, ql, sl, r, limits[layer], want_order=True, want_grid=want_grid)
+            res = deferred.add(q, s, ql, sl, r, limits[layer], want_order=True, want_grid=want_grid, reuse_grid=reuse)
             inds, order = res[0], res[1]
             orders.append((s, order))
             if want_grid:
                 pending_grids.append((len(slots), res[2]))
             return inds
-        return deferred.add(q, s, ql, sl, r, limits[layer])
+        return deferred.add(q, s, ql, sl, r, limits[layer], reuse_grid=reuse)
 
     layer_blocks = []
     input_points, input_neighbors, input_pools, input_upsamples, input_lengths = [], [], [], [], []
