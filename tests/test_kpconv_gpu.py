@@ -210,3 +210,33 @@ def test_gemm_epilogue_vs_torch(gpu, m, k, n, with_bias, with_res, slope):
     assert rel(y32.detach(), y64.detach()) < 5e-6
     for a, r in zip(leaves32, leaves64):
         assert rel(a.grad, r.grad) < 5e-5
+
+
+@pytest.mark.parametrize("m,k,n,ep", [(1500, 3840, 256, 0), (270, 7680, 512, 5), (10257, 1920, 128, 7), (4096, 1024, 96, 4),
+                                      (33, 512, 64, 3), (400000, 128, 128, 6)])
+def test_gemm_splitk_and_wave_grids_through_the_c_abi(gpu, m, k, n, ep):
+    """ws_gemm_xb_epilogue_splitk called directly (short deep products split K over up to 16 workgroup layers; the
+    last shape takes the un-split 4x1 wave grid) against float64: bias (1), residual (2), LeakyReLU (4)"""
+    from weasal_amd import _lib
+    from weasal_amd._lib import check, current_stream, ptr
+    lib = _lib.lib()
+    torch.manual_seed(k + n)
+    x = torch.randn(m, k, device=gpu)
+    b = torch.randn(k, n, device=gpu) / k ** 0.5
+    bias = torch.randn(n, device=gpu) if ep & 1 else None
+    res = torch.randn(m, n, device=gpu) if ep & 2 else None
+    y = torch.empty(m, n, device=gpu)
+    sb = lib.ws_gemm_xb_scratch_bytes(m, k, n)
+    scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=gpu)
+    check(lib.ws_gemm_xb_epilogue_splitk(ptr(x), m, k, k, ptr(b), n, ptr(bias), ptr(res), n, 1 if ep & 4 else 0, 0.1,
+                                         ptr(y), n, ptr(scratch) if sb else None, sb, current_stream()))
+    ref = x.double() @ b.double()
+    if bias is not None:
+        ref = ref + bias.double()
+    if res is not None:
+        ref = ref + res.double()
+    if ep & 4:
+        ref = torch.nn.functional.leaky_relu(ref, 0.1)
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 5e-6
+    if m < 32768 and k >= 512:
+        assert sb > 0          # these shapes are the ones that split
