@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen"])
+    ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen", "dales_deform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--contrast", type=int, default=0,
@@ -230,7 +230,7 @@ def main():
         summ = timer.summary()
         fwd = {k: v for k, v in summ.items() if k[0] == "kpconv_gather_fwd"}
         if fwd:
-            ci_dom = 32 if args.workload == "dales" else 16
+            ci_dom = 16 if args.workload == "vaihingen" else 32
             cand = [k for k in fwd if k[3] == ci_dom]
             key = max(cand or list(fwd), key=lambda k: k[1] * k[2] * k[3])
             ms_k, count = fwd[key]

@@ -326,3 +326,31 @@ def test_grid_backward_pair_conservation_full_size():
         got = torch.round(x.grad[:, 0].double() / 15).long()
         assert int(grid.overflow.item()) == 0
         assert torch.equal(got, indeg), (l, int((got != indeg).sum()))
+
+
+@pytest.mark.gpu
+def test_deformable_modulated_network_steps():
+    """BASELINE config 5's shape in fp32 (deformable + modulated KPConv in the two deepest levels, searched with the
+    deformable radius): three training steps on small spheres stay finite and move the offset / modulation weights"""
+    import numpy as np
+    from weasal_amd import config as wcfg, pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    from weasal_amd.trainer import make_optimizer, train_step
+    dev = torch.device("cuda:0")
+    cfg = wcfg.DALESDeformConfig()
+    np.random.seed(2); torch.manual_seed(2)
+    net = KPFCNN(cfg, np.arange(9), []).to(dev).train()
+    opt = make_optimizer(net, cfg)
+    names = [n for n, _ in net.named_parameters() if "offset" in n]
+    assert names, "no deformable offset parameters in the network"
+    before = {n: p.detach().clone() for n, p in net.named_parameters() if n in names[:4]}
+    pts, feats, labels, lens = synthetic.make_inputs(5, 2, 20000, 10.0, cfg.in_features_dim)
+    pts, feats, labels = (torch.from_numpy(a).to(dev) for a in (pts, feats, labels))
+    losses = []
+    for _ in range(3):
+        batch = pyramid.build_batch(cfg, pts, feats, labels, lens, [40, 50, 60, 200, 150])
+        loss, out = train_step(net, opt, batch, cfg)
+        losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and torch.isfinite(out).all()
+    after = dict(net.named_parameters())
+    assert any(not torch.equal(before[n], after[n].detach()) for n in before)

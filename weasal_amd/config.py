@@ -148,3 +148,15 @@ class Vaihingen3DPLConfig(Config):
     batch_num = 4
     dropout = 0.5
     class_w = [1, 1, 1, 1, 1, 1, 1, 1, 1]
+
+
+class DALESDeformConfig(DALESPLConfig):
+    """BASELINE config 5 in fp32: the DALES network with deformable, modulated KPConv (learned offsets +
+    modulations, models/blocks.py:244-325) in the two deepest encoder levels; the layout of the deformable
+    KP-FCNN of the KPConv paper that the reference's block_decider (blocks.py:387-427) still accepts."""
+    dataset = 'DALESDeform'
+    architecture = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb',
+                    'resnetb_strided', 'resnetb_deformable', 'resnetb_deformable_strided', 'resnetb_deformable',
+                    'nearest_upsample', 'unary', 'nearest_upsample', 'unary',
+                    'nearest_upsample', 'unary', 'nearest_upsample', 'unary']
+    modulated = True

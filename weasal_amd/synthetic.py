@@ -8,6 +8,10 @@ import numpy as np
 WORKLOADS = {
     "dales": dict(config="DALESPLConfig", radius=10.0, points=50000, spheres=8, limits=[59, 73, 81, 77, 56],
                   name="DALES_PseudoLabel KP-FCNN, in_radius=10m, 50k pts/sphere, batch=8"),
+    # config 5 shape in fp32: deformable + modulated KPConv in the two deepest levels (their searches use the
+    # deformable radius = 2 x the rigid one: about 8 x the neighbours, limits from the same 90th-percentile rule)
+    "dales_deform": dict(config="DALESDeformConfig", radius=10.0, points=50000, spheres=8, limits=[59, 73, 81, 420, 260],
+                         name="DALES deformable + modulated KP-FCNN (fp32), in_radius=10m, 50k pts/sphere, batch=8"),
     "vaihingen": dict(config="Vaihingen3DPLConfig", radius=4.0, points=3000, spheres=4, limits=[],
                       name="Vaihingen3D_PseudoLabel KP-FCNN, in_radius=4m, 3k pts/sphere, batch=4"),
 }
