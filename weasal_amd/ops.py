@@ -490,14 +490,20 @@ def closest_pool(x, inds):
 # native geometry on device tensors (K1 / K2)
 # ------------------------------------------------------------------------------------------------
 class _Workspaces:
-    """one neighbour and one subsample workspace per device (grow-only device scratch)"""
+    """one neighbour and one subsample workspace per (device, host thread): grow-only device scratch whose kernels
+    run on the calling thread's stream -- the prefetch thread and the training thread must not share one"""
 
     def __init__(self):
         self.nb = {}
         self.sub = {}
 
+    @staticmethod
+    def _key(device):
+        import threading
+        return (torch.device(device).index or 0, threading.get_ident())
+
     def neighbors(self, device):
-        key = torch.device(device).index or 0
+        key = self._key(device)
         if key not in self.nb:
             import ctypes as C
             h = C.c_void_p()
@@ -506,7 +512,7 @@ class _Workspaces:
         return self.nb[key]
 
     def subsample(self, device):
-        key = torch.device(device).index or 0
+        key = self._key(device)
         if key not in self.sub:
             import ctypes as C
             h = C.c_void_p()
