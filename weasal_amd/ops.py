@@ -246,7 +246,7 @@ def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linea
 # tall-skinny GEMMs (unary MLPs and the kernel contraction) on the f32 MFMA
 # ------------------------------------------------------------------------------------------------
 FUSED_EPILOGUE = os.environ.get("WEASAL_FUSED_EPILOGUE", "1") != "0"   # A/B switch (diagnostics)
-GEMM_MIN_ROWS = 4096     # below this the operand is no longer "tall": plain torch.matmul (rocBLAS)
+GEMM_MIN_ROWS = int(os.environ.get("WEASAL_GEMM_MIN_ROWS", "4096"))     # below this the operand is no longer "tall": plain torch.matmul (rocBLAS)
 XTY_MIN_ROWS = 0         # A/B switch: rows below which dW = x^T dy goes to rocBLAS (in the training step the MFMA
                          # reduction is ahead at every level that reaches it: 0.42 ms vs 0.54 ms per step at M = 10 257)
 
