@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_kernel(
     const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
     const float* __restrict__ dwf, const float* __restrict__ deformed_kp,
     const float* __restrict__ modulations, const float* __restrict__ d_min_d2, GeomParams g,
-    float* __restrict__ d_kp, float* __restrict__ d_mod)
+    float* __restrict__ d_kp, float* __restrict__ d_mod, int vec4)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -640,7 +640,19 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_kernel(
                 if (w[k] != 0.0f) {
                     const float* a = dwf + (q * K + k) * ci;
                     const float* b = x + idx * ci;
-                    for (int cc = 0; cc < ci; ++cc) dot = fmaf(a[cc], b[cc], dot);
+                    if (vec4) {
+                        // 16-byte pieces, four independent partial sums (the per-lane rows are L2 resident)
+                        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int cc = 0; cc < ci; cc += 4) {
+                            const float4 av = *reinterpret_cast<const float4*>(a + cc);
+                            const float4 bv = *reinterpret_cast<const float4*>(b + cc);
+                            s4.x = fmaf(av.x, bv.x, s4.x); s4.y = fmaf(av.y, bv.y, s4.y);
+                            s4.z = fmaf(av.z, bv.z, s4.z); s4.w = fmaf(av.w, bv.w, s4.w);
+                        }
+                        dot = (s4.x + s4.y) + (s4.z + s4.w);
+                    } else {
+                        for (int cc = 0; cc < ci; ++cc) dot = fmaf(a[cc], b[cc], dot);
+                    }
                 }
                 const float mod = modulations ? modulations[q * K + k] : 1.0f;
                 gm[k] += w[k] * dot;
@@ -1028,7 +1040,8 @@ int ws_kpconv_gather_bwd_geom(const float* q_pts, int64_t nq, const float* s_pts
     hipStream_t st = (hipStream_t)stream;
     kpconv_gather_bwd_geom_kernel<15><<<ws_grid(nq, 4), 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf,
                                                                        deformed_kp, modulations, d_min_d2, g,
-                                                                       d_deformed_kp, d_modulations);
+                                                                       d_deformed_kp, d_modulations,
+                                                                       (ci % 4 == 0) && aligned16(x) && aligned16(dwf));
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
