@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen", "dales_deform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
+    ap.add_argument("--dp-buckets", type=int, default=int(os.environ.get("WEASAL_DP_BUCKETS", "1")),
+                    help="N > 1 only: >1 cuts the gradient buffer into that many ranges whose all-reduce is launched "
+                         "from gradient hooks during backward (opt-in; 1 = one all-reduce after backward)")
     ap.add_argument("--contrast", type=int, default=0,
                     help="1: add KPFCNN.contrast_loss to the step (trainer_PseudoLabel.py:204-208; SURVEY 8f-2, "
                          "outside the north_star step, so off by default)")
@@ -144,7 +147,7 @@ def main():
     net.train()
     dp.broadcast_parameters(net)
     opt = make_optimizer(net, cfg)
-    sync = dp.GradSync() if world > 1 else None
+    sync = dp.GradSync(buckets=args.dp_buckets) if world > 1 else None
 
     # inputs resident in HBM before the timed region (seed = 1000*rank + step)
     nd = max(1, min(args.distinct_batches, args.steps + args.warmup))

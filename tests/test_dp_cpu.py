@@ -38,7 +38,7 @@ def _make(rank_seed):
     return cfg, net, batch
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, buckets=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
@@ -50,7 +50,7 @@ def _worker(rank, world, port, out):
     cfg, net, batch = _make(rank)
     dp.broadcast_parameters(net)
     opt = make_optimizer(net, cfg)
-    sync = dp.GradSync()
+    sync = dp.GradSync(buckets=buckets)
     with kpconv_ref.cpu_reference_mode():
         for _ in range(2):       # second step exercises the re-homed gradient views
             loss, _o = train_step(net, opt, batch, cfg, grad_sync=sync)
@@ -62,11 +62,13 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_step_matches_mean_gradient():
+@pytest.mark.parametrize("buckets", [1, 3])
+def test_two_rank_step_matches_mean_gradient(buckets):
+    """buckets = 3: the opt-in overlapped form (asynchronous all-reduce per range, launched from gradient hooks)"""
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, buckets), nprocs=world, join=True)
     a, b = out[0], out[1]
     for k in a:
         if k.startswith("__"):
