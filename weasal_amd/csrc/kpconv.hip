@@ -829,7 +829,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
             cnt = GRID_SLAB;
         }
         wave_lds_sync();
-        // ---- order by index: rank by counting (distinct indices), then permute through registers
+        // ---- order by index: rank by counting (distinct indices), then permute through registers; only as many
+        //      entries per lane as the in-degree needs (1 for <= 64 incoming pairs)
         {
             float4 e[EPL];
             int rk[EPL];
@@ -838,10 +839,20 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
                 e[u] = lane + 64 * u < cnt ? slab[lane + 64 * u] : make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
                 rk[u] = 0;
             }
-            for (int i = 0; i < cnt; ++i) {
-                const int ki = __float_as_int(slab[i].w);
+            if (cnt <= 64) {
+                for (int i = 0; i < cnt; ++i) rk[0] += __float_as_int(slab[i].w) < __float_as_int(e[0].w) ? 1 : 0;
+            } else if (cnt <= 128) {
+                for (int i = 0; i < cnt; ++i) {
+                    const int ki = __float_as_int(slab[i].w);
+                    rk[0] += ki < __float_as_int(e[0].w) ? 1 : 0;
+                    rk[1] += ki < __float_as_int(e[1].w) ? 1 : 0;
+                }
+            } else {
+                for (int i = 0; i < cnt; ++i) {
+                    const int ki = __float_as_int(slab[i].w);
 #pragma unroll
-                for (int u = 0; u < EPL; ++u) rk[u] += ki < __float_as_int(e[u].w) ? 1 : 0;
+                    for (int u = 0; u < EPL; ++u) rk[u] += ki < __float_as_int(e[u].w) ? 1 : 0;
+                }
             }
             wave_lds_sync();
 #pragma unroll
