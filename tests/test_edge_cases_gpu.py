@@ -132,3 +132,46 @@ def test_pools_odd_channels(gpu, c):
     g2 = ops.closest_pool(xg2, t(inds).to(gpu))
     (g2 * t(dy).to(gpu)).sum().backward()
     assert torch.equal(g2.detach().cpu(), w2.detach()) and rel(xg2.grad, xc2.grad) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n", [(0, 16), (1, 4), (130, 9), (5000, 33), (4099, 128)])
+def test_act_bwd_colsum_edge_shapes(m, n):
+    """ws_act_bwd_colsum: empty input, single row, odd widths (scalar path), rows that do not fill a chunk"""
+    from weasal_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(m + n)
+    dy, y = torch.randn(m, n, device=dev), torch.randn(m, n, device=dev)
+    for act in (True, False):
+        dz, cs = ops._act_bwd_colsum(dy, y if act else None, 0.1 if act else None, True)
+        ref = torch.where(y > 0, dy, dy * 0.1) if act else dy
+        assert torch.equal(dz, ref)
+        want = ref.double().sum(0)
+        assert cs.shape == (n,)
+        assert float((cs.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) if m else float(cs.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_contrast_rows_small_slice_and_wide_logits():
+    """ws_contrast_rows with fewer slice rows than 1000, 16 logit channels, and a point that is its own slice row"""
+    from weasal_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    n, c, s = 777, 16, 130
+    on = torch.nn.functional.normalize(torch.randn(n, c, device=dev), dim=1).requires_grad_(True)
+    slc = torch.randint(0, n, (s,), device=dev); slc[0] = 5
+    cert = torch.rand(n, device=dev) > 0.3
+    lbl = torch.randint(0, 7, (n,), device=dev)
+    loss = ops.contrast_rows(on, on[slc], slc, cert, lbl, 0.1, 1e-8)
+    # dense restatement of architectures.py:455-497 in float64
+    o = on.detach().double()
+    mul = o @ o[slc].T / 0.1
+    use = (torch.arange(n, device=dev)[:, None] != slc[None, :]) & (cert[slc][None, :] == cert[:, None])
+    pos = use & (lbl[slc][None, :] == lbl[:, None])
+    lg = mul - mul.max(1, keepdim=True)[0]
+    e = (lg.exp() * use).sum(1, keepdim=True)
+    lp = (lg - torch.log(e + 1e-8)) * use
+    ref = -0.1 * (pos * lp).sum(1) / (pos.sum(1) + 1e-12)
+    assert float((loss.detach().double() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    loss.sum().backward()
+    assert bool(torch.isfinite(on.grad).all())
