@@ -24,17 +24,23 @@ def p2p_fitting_regularizer(net):
     repulsion of the deformed kernel points closer than `repulse_extent` (architectures.py:24-57)."""
     fitting_loss = 0
     repulsive_loss = 0
-    for m in net.modules():
-        if not (isinstance(m, KPConv) and m.deformable):
-            continue
+    layers = getattr(net, "_deformable_layers", None)
+    if layers is None:                      # the module tree is static: scan it once, not every step
+        layers = [m for m in net.modules() if isinstance(m, KPConv) and m.deformable]
+        net._deformable_layers = layers
+    for m in layers:
         kp_min_d2 = m.min_d2 / (m.KP_extent ** 2)
         fitting_loss = fitting_loss + net.l1(kp_min_d2, torch.zeros_like(kp_min_d2))
         locs = m.deformed_KP / m.KP_extent                                   # [N, K, 3]
-        for i in range(net.K):
-            others = torch.cat([locs[:, :i, :], locs[:, i + 1:, :]], dim=1).detach()
-            dist = torch.sqrt(torch.sum((others - locs[:, i:i + 1, :]) ** 2, dim=2))
-            rep = torch.sum(torch.clamp_max(dist - net.repulse_extent, max=0.0) ** 2, dim=1)
-            repulsive_loss = repulsive_loss + net.l1(rep, torch.zeros_like(rep)) / net.K
+        # the reference loops over the K kernel points (:45-51): point i against the DETACHED other K-1 points.
+        # Same terms in one pass: dist[n, i, j] = |locs[n, i] - stopgrad(locs[n, j])|, the j == i column masked out.
+        diff = locs.unsqueeze(2) - locs.detach().unsqueeze(1)                # [N, K(i), K(j), 3]
+        off_diag = ~torch.eye(net.K, dtype=torch.bool, device=locs.device)
+        # + 1 on the (masked) diagonal: sqrt(0) would put an infinite derivative times the zero mask into the gradient
+        dist = torch.sqrt(torch.sum(diff ** 2, dim=3) + (~off_diag).to(locs.dtype))
+        pen = torch.clamp_max(dist - net.repulse_extent, max=0.0) ** 2
+        rep = torch.sum(pen * off_diag, dim=2)                               # [N, K]: sum over the other points
+        repulsive_loss = repulsive_loss + torch.sum(torch.mean(torch.abs(rep), dim=0)) / net.K
     return net.deform_fitting_power * (2 * fitting_loss + repulsive_loss)
 
 
