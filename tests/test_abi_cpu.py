@@ -132,3 +132,21 @@ def test_calibration_percentiles():
     lim = limits_from_histograms(hists, 0.9)
     for c, l in zip(counts, lim):
         assert (c <= l).mean() >= 0.9 and (c <= l - 1).mean() < 0.9
+
+
+def test_batch_limit_controller_converges_on_a_synthetic_sampler():
+    """calibration.BatchLimitController (DALES_PseudoLabel.py:1190-1241): with spheres of ~N points a batch of budget L
+    holds about L / N spheres; the loop must settle on the budget that gives the target sphere count"""
+    import numpy as np
+    from weasal_amd.calibration import BatchLimitController
+    rng = np.random.default_rng(0)
+    ctl = BatchLimitController(target_b=8, batch_limit=1.0, expected_n=20000)
+    limit = ctl.batch_limit
+    for _ in range(6000):
+        sizes = rng.normal(20000, 1500, size=64).clip(5000)
+        b = int(np.searchsorted(np.cumsum(sizes), max(limit, 0.0))) + 1     # spheres that fit the point budget
+        limit = ctl.update(b)
+        if ctl.converged:
+            break
+    assert ctl.converged and abs(ctl.estim_b - 8) < 0.5
+    assert 6 * 20000 < ctl.batch_limit < 10 * 20000
