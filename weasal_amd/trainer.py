@@ -32,6 +32,8 @@ def train_step(net, optimizer, batch, config, grad_sync=None, epoch=None):
     loss = net.loss(outputs, batch.labels)
     if epoch is not None and epoch >= getattr(config, 'contrast_start', 1 << 30):
         loss = loss + net.contrast_loss(outputs, batch.labels, config)
+    if grad_sync is not None and hasattr(grad_sync, "arm"):
+        grad_sync.arm()          # the overlapped exchange's gradient hooks run for this backward only
     loss.backward()
     if grad_sync is not None:
         grad_sync(net)
