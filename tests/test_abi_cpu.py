@@ -150,3 +150,44 @@ def test_batch_limit_controller_converges_on_a_synthetic_sampler():
             break
     assert ctl.converged and abs(ctl.estim_b - 8) < 0.5
     assert 6 * 20000 < ctl.batch_limit < 10 * 20000
+
+
+def test_facades_raise_in_a_forked_child_of_a_gpu_parent(monkeypatch):
+    """The reference's DataLoader workers are forked after the net went to the GPU (train_DALES_PseudoLabel.py:291-296):
+    in such a child the facades must raise the reference's RuntimeError with the remedy, not crash or hang.  No GPU here:
+    the 'runtime was live in the parent' condition is simulated (torch.cuda.is_initialized -> True at fork time)."""
+    import os
+    import torch
+    from weasal_amd.cpp_wrappers import _device
+    from weasal_amd.cpp_wrappers.cpp_neighbors import radius_neighbors as rn
+    from weasal_amd.cpp_wrappers.cpp_subsampling import grid_subsampling as gs
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                   # child: report what the facades did, never return into pytest
+        os.close(r)
+        msgs = []
+        p = np.zeros((5, 3), np.float32)
+        for call in (lambda: rn.batch_query(p, p, [5], [5], radius=1.0), lambda: gs.subsample_batch(p, [5], sampleDl=0.5)):
+            try:
+                call()
+                msgs.append("no error")
+            except RuntimeError as e:
+                msgs.append(str(e))
+            except BaseException as e:             # noqa: BLE001
+                msgs.append("other: %r" % (e,))
+        os.write(w, "\n".join(msgs).encode())
+        os._exit(0)
+    os.close(w)
+    data = b""
+    while True:
+        chunk = os.read(r, 65536)
+        if not chunk:
+            break
+        data += chunk
+    os.waitpid(pid, 0)
+    msgs = data.decode().split("\n")
+    assert len(msgs) == 2
+    for m in msgs:
+        assert m == _device.FORK_MESSAGE and "spawn" in m
+    assert not _device._forked_from_gpu_parent     # the parent itself is unaffected

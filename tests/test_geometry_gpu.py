@@ -201,3 +201,45 @@ def test_dropin_import_paths(gpu):
         sys.path.remove(d)
         for name in [m for m in list(sys.modules) if m.split(".")[0] in ("models", "cpp_wrappers", "kernels")]:
             del sys.modules[name]
+
+
+def _spawn_facade_worker(conn):
+    """runs in a fresh ("spawn") child: its own HIP runtime, the numpy facades with the reference's signatures"""
+    import numpy as np
+    try:
+        from weasal_amd.cpp_wrappers.cpp_neighbors import radius_neighbors as cpp_neighbors
+        from weasal_amd.cpp_wrappers.cpp_subsampling import grid_subsampling as cpp_subsampling
+        rng = np.random.default_rng(5)
+        pts = rng.uniform(-2, 2, size=(2500, 3)).astype(np.float32)
+        lens = np.array([1500, 1000], np.int32)
+        inds = cpp_neighbors.batch_query(pts, pts, lens, lens, radius=0.55)
+        sub = cpp_subsampling.subsample_batch(pts, lens, sampleDl=0.4, max_p=0, verbose=0)
+        conn.send(("ok", pts, lens, inds, sub[0], sub[1]))
+    except BaseException as e:             # noqa: BLE001
+        conn.send(("error", repr(e)))
+    conn.close()
+
+
+@pytest.mark.timeout(600)
+def test_facades_from_a_spawn_worker(gpu):
+    """The reference calls the two modules from DataLoader worker processes (datasets/common.py:56-74,126-175,185-196).
+    A worker started with the "spawn" method is a fresh child with its own HIP runtime: the facades work there while
+    the parent (this process) holds an initialised runtime of its own.  (Fork-started workers cannot: they raise,
+    tests/test_abi_cpu.py::test_facades_raise_in_a_forked_child_of_a_gpu_parent.)"""
+    import multiprocessing as mp
+    from oracle import geom
+    torch.zeros(1, device=gpu)                               # the parent's runtime is live
+    ctx = mp.get_context("spawn")
+    parent, child = ctx.Pipe()
+    proc = ctx.Process(target=_spawn_facade_worker, args=(child,))
+    proc.start()
+    assert parent.poll(500), "spawn worker did not answer"
+    msg = parent.recv()
+    proc.join(60)
+    assert msg[0] == "ok", msg
+    _, pts, lens, inds, sub_p, sub_b = msg
+    want = geom.batch_query(pts, pts, lens, lens, 0.55)
+    assert inds.dtype == np.int32
+    assert_neighbors_equal(pts, pts, inds, want, False)
+    want_p, want_b = geom.subsample_batch(pts, lens, sampleDl=0.4)[:2]
+    assert np.array_equal(sub_p, want_p) and np.array_equal(sub_b, want_b)

@@ -9,10 +9,13 @@ RuntimeError("Error") (:201-205).  The computation runs on the current HIP devic
 (weasal_amd/csrc/neighbors.hip); arrays go host -> HBM -> host, so use the device-tensor form
 ``weasal_amd.ops.radius_neighbors`` / ``weasal_amd.pyramid`` inside a training step.
 
-HIP cannot be initialised in a forked child after the parent touched the GPU: call this module
-from the main process (DataLoader num_workers=0) or from workers started with the "spawn" method.
+HIP cannot be used in a forked child after the parent touched the GPU (the situation of the reference's
+fork-started DataLoader workers): the call then raises RuntimeError with the remedy (weasal_amd/cpp_wrappers/
+_device.py) -- use workers started with the "spawn" method, num_workers=0, or the device pyramid.
 """
 import numpy as np
+
+from weasal_amd.cpp_wrappers import _device
 
 
 def _as(obj, dtype, what):
@@ -40,7 +43,7 @@ def batch_query(queries, supports, q_batches, s_batches, *, radius=0.1):
     qb, sb = qb.reshape(-1), sb.reshape(-1)
     if qb.shape[0] != sb.shape[0]:
         raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = _device.current_device()
     try:
         out = ops.radius_neighbors(torch.from_numpy(q).to(dev), torch.from_numpy(s).to(dev), qb, sb,
                                    float(np.float32(radius)), dtype=torch.int32)

@@ -13,6 +13,8 @@ fork caveat.
 """
 import numpy as np
 
+from weasal_amd.cpp_wrappers import _device
+
 
 def _as(obj, dtype, what):
     try:
@@ -42,7 +44,7 @@ def _run(points, batches, features, classes, sampleDl, max_p, batched):
     if c is not None and (c.ndim > 2 or c.shape[0] != p.shape[0]):
         raise RuntimeError("Wrong dimensions : classes.shape is not (N,) or (N, d)")
     lens = b.reshape(-1) if batched else np.array([p.shape[0]], np.int32)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = _device.current_device()
     t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
     try:
         res = ops.grid_subsample(t(p), lens, float(np.float32(sampleDl)), max_p=int(max_p), features=t(f),
