@@ -304,6 +304,62 @@ int ws_contrast_rows_bwd(const float* on, int64_t n, int32_t c, const float* xs,
                          const float* den, const float* npos, const float* g, float* d_on, float* d_xs, void* scratch,
                          void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * bf16-feature path (BASELINE.json configs[4]: "deformable-KPConv ... bf16"; SURVEY.md section 8d C5:
+ * feature rows / weights bf16 in HBM, fp32 accumulate, geometry fp32).  The reference has no reduced-precision
+ * path; these entries are the bf16-row forms of the operators above and replace the same reference lines
+ * (models/blocks.py:36-134 pools, :238-374 KPConv, :370-374 / :490-501 the dense products).  Feature rows are
+ * bf16 (uint16_t bit patterns, round-to-nearest-even on store), everything geometric (points, kernel points,
+ * deformed_kp, modulations, min_d2 and their gradients) stays f32; sums run in f32 and are rounded once.
+ * Rows need c % 4 == 0 and 8-byte alignment (WS_ERR_INVALID otherwise -- the 3-channel input layer stays f32).
+ * ------------------------------------------------------------------------------------------ */
+int ws_kpconv_gather_fwd_bf16(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                              const uint16_t* x, int32_t ci, const float* kernel_points, int32_t k, const float* deformed_kp,
+                              const float* modulations, float extent, int32_t influence, int32_t aggregation,
+                              const int32_t* order, uint16_t* wf, float* min_d2, void* stream);
+int ws_kpconv_gather_bwd_x_bf16(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                                const int32_t* t_offsets, const int32_t* t_pairs, const uint16_t* dwf, int32_t ci,
+                                const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                                float extent, int32_t influence, int32_t aggregation, const int32_t* order, uint16_t* dx,
+                                void* stream);
+int ws_kpconv_gather_bwd_x_grid_bf16(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                     const uint64_t* key_last, float radius, const uint16_t* dwf, int32_t ci,
+                                     const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                                     float extent, int32_t influence, int32_t aggregation, const int32_t* order, uint16_t* dx,
+                                     int32_t* overflow, void* stream);
+int ws_kpconv_gather_bwd_geom_bf16(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                                   const uint16_t* x, int32_t ci, const uint16_t* dwf, const float* kernel_points, int32_t k,
+                                   const float* deformed_kp, const float* modulations, const float* d_min_d2, float extent,
+                                   int32_t influence, int32_t aggregation, float* d_deformed_kp, float* d_modulations,
+                                   void* stream);
+int ws_max_pool_fwd_bf16(const uint16_t* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                         uint16_t* out, int32_t* arg, void* stream);
+int ws_max_pool_bwd_bf16(const uint16_t* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                         const int32_t* t_pairs, int64_t ns, uint16_t* dx, void* stream);
+int ws_closest_pool_fwd_bf16(const uint16_t* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                             uint16_t* out, void* stream);
+int ws_closest_pool_bwd_bf16(const uint16_t* dy, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                             const int32_t* t_pairs, int64_t ns, uint16_t* dx, void* stream);
+
+/* Y[m,n] = act( X[m,k] * Bt[n,k]^T + bias + residual ) on v_mfma_f32_32x32x16_bf16: X, Bt, residual bf16 rows
+ * (K-contiguous: Bt is nn.Linear's own [out,in] layout, blocks.py:490), bias f32 [n], fp32 accumulate, one rounding
+ * to bf16 on store -- or f32 output (out_f32 = 1: the logits, the offsets of deformable KPConv blocks.py:244-267).
+ * k % 32 == 0, ldx % 8 == 0, ldbt % 8 == 0, 16-byte aligned x / bt (WS_ERR_INVALID otherwise; callers keep such
+ * products on the f32 kernels).  act: 0 = identity, 1 = LeakyReLU(slope). */
+int ws_gemm_xbt_bf16(const uint16_t* x, int64_t m, int32_t k, int64_t ldx, const uint16_t* bt, int32_t n, int64_t ldbt,
+                     const float* bias, const uint16_t* residual, int64_t ldr, int32_t act, float slope,
+                     void* y, int64_t ldy, int32_t out_f32, void* stream);
+/* out[k,n] f32 = X[m,k]^T * Y[m,n] with bf16 rows (the fp32 master gradient dW; exact products, fp32 sums on the
+ * f32 MFMA); scratch as ws_gemm_xty_scratch_bytes(m, k, n). */
+int ws_gemm_xty_bf16(const uint16_t* x, int64_t m, int32_t k, int64_t ldx, const uint16_t* y, int32_t n, int64_t ldy,
+                     float* out, void* scratch, void* stream);
+/* dz = dy * LeakyReLU'(y) as bf16 rows (y = the layer's bf16 output, NULL = identity: then dz may be NULL) and the f32
+ * column sums of dz (colsum NULL = not wanted); dy is bf16, or f32 when dy_f32 = 1.  n % 4 == 0. */
+int64_t ws_act_bwd_colsum_bf16_scratch_bytes(int64_t m, int32_t n);
+int ws_act_bwd_colsum_bf16(const void* dy, int32_t dy_f32, int64_t m, int32_t n, int64_t lddy, const uint16_t* y, int64_t ldy,
+                           float slope, uint16_t* dz, int64_t lddz, float* colsum, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

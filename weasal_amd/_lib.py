@@ -70,6 +70,23 @@ SIGNATURES = {
     "ws_grid_subsample_fill": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws_rotate_clouds": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
     "ws_rotate_clouds_host": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
+    # bf16-feature path (same argument lists as the f32 entries; uint16_t* rows)
+    "ws_kpconv_gather_fwd_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp,
+                                           _f32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ws_kpconv_gather_bwd_x_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32,
+                                             _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp]),
+    "ws_kpconv_gather_bwd_geom_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _i32,
+                                                _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp]),
+    "ws_kpconv_gather_bwd_x_grid_bf16": (C.c_int, [_vp, _i64, _vp, _i32, _i64, _vp, C.c_float, _vp, _i32, _vp, _i32, _vp, _vp,
+                                                   C.c_float, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ws_max_pool_fwd_bf16": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "ws_max_pool_bwd_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "ws_closest_pool_fwd_bf16": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
+    "ws_closest_pool_bwd_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "ws_gemm_xbt_bf16": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _i64, _i32, _f32, _vp, _i64, _i32, _vp]),
+    "ws_gemm_xty_bf16": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "ws_act_bwd_colsum_bf16_scratch_bytes": (_i64, [_i64, _i32]),
+    "ws_act_bwd_colsum_bf16": (C.c_int, [_vp, _i32, _i64, _i32, _i64, _vp, _i64, C.c_float, _vp, _i64, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -118,6 +118,11 @@ class KPFCNN(nn.Module):
         # is upsampled; identical in exact arithmetic to architectures.py:339-343 (the gather of a row
         # commutes with a per-row linear map), ~2.3x fewer decoder FLOPs, no [N_fine, C_up + C_skip] tensor.
         self.fuse_decoder = True
+        # BASELINE config 5: feature rows (activations, their gradients, weighted features) bf16 in HBM, fp32 accumulate,
+        # fp32 master weights; the 3-channel input layer and the 9 logits stay f32
+        self.feature_dtype = torch.bfloat16 if getattr(config, 'feature_dtype', 'f32') == 'bf16' else torch.float32
+        if self.feature_dtype == torch.bfloat16:
+            self.head_softmax.out_f32 = True
 
     def _fused_upsample_unary(self, x, skip, up_block, unary, batch):
         c_up = x.shape[1]
@@ -137,6 +142,8 @@ class KPFCNN(nn.Module):
             if block_i in self.encoder_skips:
                 skips.append(x)
             x = block_op(x, batch)
+            if block_i == 0 and self.feature_dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[1] % 32 == 0:
+                x = x.to(torch.bfloat16)     # the 3-channel input layer ran in f32; bf16 rows from here on
         nd = len(self.decoder_blocks)
         block_i = 0
         while block_i < nd:

@@ -111,9 +111,11 @@ class KPConv(nn.Module):
         k_points = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
         return Parameter(torch.tensor(k_points, dtype=torch.float32), requires_grad=False)
 
-    def forward(self, q_pts, s_pts, neighb_inds, x, _bias=None, _slope=None):
+    def forward(self, q_pts, s_pts, neighb_inds, x, _bias=None, _slope=None, _out_f32=False):
         """`_bias` / `_slope` (used by the blocks of this module only): the BatchNormBlock bias and the
-        LeakyReLU that follow the convolution, applied in the epilogue of the contraction GEMM."""
+        LeakyReLU that follow the convolution, applied in the epilogue of the contraction GEMM.
+        bf16 feature rows (x.dtype bfloat16, BASELINE config 5) run the bf16-row kernels; `_out_f32` keeps the
+        output in f32 (the offsets of a deformable convolution: geometry stays f32)."""
         if self.KP_influence not in ops.INFLUENCE:
             raise ValueError('Unknown influence function type (config.KP_influence)')
         if self.aggregation_mode not in ops.AGGREGATION:
@@ -123,7 +125,7 @@ class KPConv(nn.Module):
         modulations = None
         if self.deformable:
             # offsets from a rigid KPConv on the same neighbourhood (blocks.py:244-267)
-            self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x) + self.offset_bias
+            self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x, _out_f32=True) + self.offset_bias
             nkp = self.p_dim * self.K
             if self.modulated:
                 unscaled = self.offset_features[:, :nkp].reshape(-1, self.K, self.p_dim)
@@ -140,6 +142,10 @@ class KPConv(nn.Module):
         if self.deformable:
             self.min_d2 = min_d2                                                     # blocks.py:304
         # dense contraction over (kernel point, input channel): blocks.py:370-374
+        if wf.dtype == torch.bfloat16:
+            return ops.matmul_epilogue(wf.reshape(wf.shape[0], -1),
+                                       self.weights.reshape(self.K * self.in_channels, self.out_channels),
+                                       bias=_bias, slope=_slope, out_f32=_out_f32)
         return ops.matmul_epilogue(wf.reshape(wf.shape[0], -1),
                                    self.weights.reshape(self.K * self.in_channels, self.out_channels),
                                    bias=_bias, slope=_slope)
@@ -223,6 +229,7 @@ class UnaryBlock(nn.Module):
         self.batch_norm = BatchNormBlock(out_dim, self.use_bn, self.bn_momentum)
         if not no_relu:
             self.leaky_relu = nn.LeakyReLU(0.1)
+        self.out_f32 = False     # bf16 feature rows only: keep this block's output in f32 (the logits)
 
     def forward(self, x, batch=None):
         return self.forward_fused(x)
@@ -232,6 +239,9 @@ class UnaryBlock(nn.Module):
         slope_override: activation applied although the block itself has no_relu (the residual sum of
         ResnetBottleneckBlock, blocks.py:709)."""
         slope = slope_override if slope_override is not None else (None if self.no_relu else 0.1)
+        if x.dtype == torch.bfloat16:
+            return ops.matmul_epilogue(x, self.mlp.weight.t(), bias=self.batch_norm.epilogue_bias(), residual=residual,
+                                       slope=slope, out_f32=self.out_f32)
         return ops.matmul_epilogue(x, self.mlp.weight.t(), bias=self.batch_norm.epilogue_bias(), residual=residual,
                                    slope=slope)
 

@@ -151,12 +151,19 @@ class Vaihingen3DPLConfig(Config):
 
 
 class DALESDeformConfig(DALESPLConfig):
-    """BASELINE config 5 in fp32: the DALES network with deformable, modulated KPConv (learned offsets +
-    modulations, models/blocks.py:244-325) in the two deepest encoder levels; the layout of the deformable
-    KP-FCNN of the KPConv paper that the reference's block_decider (blocks.py:387-427) still accepts."""
+    """BASELINE config 5 as SURVEY.md section 8d specifies it: the DALES network with every `resnetb` block replaced by
+    `resnetb_deformable` (learned offsets, models/blocks.py:244-325) and `modulated = True` (:256,:366-367),
+    deform_radius 5.0 -- so every level is searched with the deformable radius r * deform_radius / conv_radius = 2 r
+    (datasets/common.py:498-503: about 8 x the neighbours) -- and feature rows / weights bf16 with fp32 accumulate
+    (`feature_dtype`; the reference has no reduced-precision path: fp32 masters, bf16 rows in HBM)."""
     dataset = 'DALESDeform'
-    architecture = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb',
-                    'resnetb_strided', 'resnetb_deformable', 'resnetb_deformable_strided', 'resnetb_deformable',
-                    'nearest_upsample', 'unary', 'nearest_upsample', 'unary',
-                    'nearest_upsample', 'unary', 'nearest_upsample', 'unary']
+    architecture = [b.replace('resnetb', 'resnetb_deformable') for b in _PL_ARCH]
     modulated = True
+    deform_radius = 5.0
+    feature_dtype = 'bf16'
+
+
+class DALESDeformF32Config(DALESDeformConfig):
+    """the same network with f32 rows (A/B of the bf16 path; oracle comparisons at 1e-4)"""
+    dataset = 'DALESDeformF32'
+    feature_dtype = 'f32'

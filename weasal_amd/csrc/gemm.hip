@@ -16,6 +16,7 @@
 // order.  A operand lane map: A[i = lane&31][k = lane>>5]; B: B[k = lane>>5][j = lane&31];
 // C/D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  (cdna_hip_programming.md section 3).
 #include "ws_common.h"
+#include "ws_bf16.h"
 
 namespace {
 
@@ -473,11 +474,36 @@ __global__ __launch_bounds__(256) void gemm_xty_kernel(const float* __restrict__
 // of a workgroup are WK x WN tiles x WR row groups (row groups are summed through LDS at the end,
 // fixed order).  Loads run U steps ahead of the MFMAs; no barrier in the main loop.
 // ---------------------------------------------------------------------------------------------
-template <int KT, int NT, int WK, int WN>
-__global__ __launch_bounds__(256) void gemm_xty2_kernel(const float* __restrict__ x, int64_t m, int k, int64_t ldx,
-                                                         const float* __restrict__ yy, int n, int64_t ldy,
+// TI = float, or bf16_t for the bf16-feature path: 2-byte operand loads widened exactly to f32 in registers (the
+// products and sums stay fp32: dW is the fp32 master gradient).
+template <int KT, typename TI>
+__device__ __forceinline__ void xty_load_cols(__amdgpu_buffer_rsrc_t srd, int off, int soff, float (&out)[KT])
+{
+    if constexpr (sizeof(TI) == 4) {
+        if constexpr (KT == 2) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(srd, off, soff, 0);
+            out[0] = __uint_as_float(v.x);
+            out[1] = __uint_as_float(v.y);
+        } else {
+            out[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srd, off, soff, 0));
+        }
+    } else {
+        if constexpr (KT == 2) {
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(srd, off, soff, 0);
+            out[0] = ws_bf_lo(v);
+            out[1] = ws_bf_hi(v);
+        } else {
+            out[0] = ws_bf_lo((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(srd, off, soff, 0));
+        }
+    }
+}
+
+template <int KT, int NT, int WK, int WN, typename TI = float>
+__global__ __launch_bounds__(256) void gemm_xty2_kernel(const TI* __restrict__ x, int64_t m, int k, int64_t ldx,
+                                                         const TI* __restrict__ yy, int n, int64_t ldy,
                                                          float* __restrict__ partial, int64_t chunk)
 {
+    constexpr int ES = (int)sizeof(TI);
     constexpr int WR = 4 / (WK * WN);
     constexpr int U = 8;                                   // steps (row pairs) per block
     __shared__ float red[(WR > 1) ? WK * WN * KT * NT * 16 * 64 : 1];
@@ -510,31 +536,19 @@ __global__ __launch_bounds__(256) void gemm_xty2_kernel(const float* __restrict_
     // scalar offset -> no vector address arithmetic next to the MFMAs, and rows past the end of the
     // chunk read as 0 through the descriptor's bounds check (no tail code)
     const int64_t nrows = mend - mbeg;
-    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + mbeg * ldx), 0,
-                                                        (int)(((nrows - 1) * ldx + k) * 4), 0x00020000);
-    const auto ysrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(yy + mbeg * ldy), 0,
-                                                        (int)(((nrows - 1) * ldy + n) * 4), 0x00020000);
-    const int xoff = (int)(h * ldx + xc) * 4, yoff = (int)(h * ldy + yc) * 4;
-    const int xstep = (int)ldx * 8, ystep = (int)ldy * 8;      // bytes per step (two rows)
+    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI*>(x + mbeg * ldx), 0,
+                                                        (int)(((nrows - 1) * ldx + k) * ES), 0x00020000);
+    const auto ysrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI*>(yy + mbeg * ldy), 0,
+                                                        (int)(((nrows - 1) * ldy + n) * ES), 0x00020000);
+    const int xoff = (int)(h * ldx + xc) * ES, yoff = (int)(h * ldy + yc) * ES;
+    const int xstep = (int)ldx * 2 * ES, ystep = (int)ldy * 2 * ES;      // bytes per step (two rows)
     float xa[2][U][KT], ya[2][U][NT];
     auto load_block = [&](int blk, int slot) {                 // blk = index of the 2U-row block in the chunk (uniform)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int step = blk * U + u;
-            if (KT == 2) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xsrd, xoff, step * xstep, 0);
-                xa[slot][u][0] = __uint_as_float(v.x);
-                xa[slot][u][KT - 1] = __uint_as_float(v.y);
-            } else {
-                xa[slot][u][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xsrd, xoff, step * xstep, 0));
-            }
-            if (NT == 2) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ysrd, yoff, step * ystep, 0);
-                ya[slot][u][0] = __uint_as_float(v.x);
-                ya[slot][u][NT - 1] = __uint_as_float(v.y);
-            } else {
-                ya[slot][u][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ysrd, yoff, step * ystep, 0));
-            }
+            xty_load_cols<KT, TI>(xsrd, xoff, step * xstep, xa[slot][u]);
+            xty_load_cols<NT, TI>(ysrd, yoff, step * ystep, ya[slot][u]);
         }
     };
     auto compute = [&](int slot) {
@@ -928,6 +942,57 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
 #undef WS_XTY_K
 #undef WS_XTY
     }
+    WS_LAUNCH_CHECK();
+    if (chunks > 1) {
+        const int64_t elems = (int64_t)k * n;
+        reduce_partials_kernel<<<(unsigned)ws_ceil_div(elems, 32), 256, 0, st>>>(partial, elems, chunks, out);
+        WS_LAUNCH_CHECK();
+    }
+    return WS_OK;
+}
+
+
+// dW = X^T dY with bf16 rows (BASELINE config 5): the LDS-free reduction above with 2-byte operand loads.
+// Requirements: k, n even or <= 32 handled by the one-column form; every shape of the bf16 path qualifies.
+int ws_gemm_xty_bf16(const uint16_t* x, int64_t m, int32_t k, int64_t ldx, const uint16_t* y, int32_t n, int64_t ldy,
+                     float* out, void* scratch, void* stream)
+{
+    WS_REQUIRE(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
+    WS_REQUIRE(out, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 0) {
+        WS_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)k * n, st));
+        return WS_OK;
+    }
+    WS_REQUIRE(x && y && scratch, "NULL argument");
+    const int64_t chunk = xty_chunk(m, k, n);
+    const int chunks = (int)ws_ceil_div(m, chunk);
+    WS_REQUIRE(chunk * (ldx > ldy ? ldx : ldy) * 2 < (1ll << 31), "operand exceeds the 32-bit buffer offsets");
+    float* partial = chunks == 1 ? out : (float*)scratch;
+    const bf16_t* xb = reinterpret_cast<const bf16_t*>(x);
+    const bf16_t* yb = reinterpret_cast<const bf16_t*>(y);
+    const bool al4x = (reinterpret_cast<uintptr_t>(x) & 3u) == 0 && ldx % 2 == 0 && k % 2 == 0;
+    const bool al4y = (reinterpret_cast<uintptr_t>(y) & 3u) == 0 && ldy % 2 == 0 && n % 2 == 0;
+    const int kt = (k > 32 && al4x) ? 2 : 1, nt = (n > 32 && al4y) ? 2 : 1;
+    const int wk = k > 32 * kt ? 2 : 1;
+    const int wn = (n > 32 * nt && wk == 1) || (n > 32 * nt && k > 32 * kt) ? 2 : 1;
+#define WS_XTY2B(KTV, NTV, WKV, WNV)                                                                                  \
+    gemm_xty2_kernel<KTV, NTV, WKV, WNV, bf16_t><<<dim3(chunks, (unsigned)ws_ceil_div(k, 32 * KTV * WKV),             \
+                                                        (unsigned)ws_ceil_div(n, 32 * NTV * WNV)), 256, 0, st>>>(     \
+        xb, m, k, ldx, yb, n, ldy, partial, chunk)
+#define WS_XTY2B_W(KTV, NTV)                          \
+    do {                                              \
+        if (wk == 2 && wn == 2) WS_XTY2B(KTV, NTV, 2, 2); \
+        else if (wk == 2) WS_XTY2B(KTV, NTV, 2, 1);   \
+        else if (wn == 2) WS_XTY2B(KTV, NTV, 1, 2);   \
+        else WS_XTY2B(KTV, NTV, 1, 1);                \
+    } while (0)
+    if (kt == 2 && nt == 2) WS_XTY2B_W(2, 2);
+    else if (kt == 2) WS_XTY2B_W(2, 1);
+    else if (nt == 2) WS_XTY2B_W(1, 2);
+    else WS_XTY2B_W(1, 1);
+#undef WS_XTY2B_W
+#undef WS_XTY2B
     WS_LAUNCH_CHECK();
     if (chunks > 1) {
         const int64_t elems = (int64_t)k * n;

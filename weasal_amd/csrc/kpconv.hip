@@ -11,6 +11,7 @@
 // above the kernels.
 #include "ws_common.h"
 #include "ws_grid.h"
+#include "ws_bf16.h"
 
 namespace {
 
@@ -115,15 +116,15 @@ __device__ __forceinline__ float kp_weight(float d2, const GeomParams& g, float 
 // 16-byte piece of a feature row, branch free.  VEC: the caller guarantees ch+3 < ci (or passes
 // ch = 0 together with a zero weight).  !VEC: element-wise with clamped columns; columns >= ci
 // are zeroed.
-template <bool VEC>
-__device__ __forceinline__ float4 load_row_piece(const float* __restrict__ base, unsigned row, int ci, int ch)
+template <bool VEC, typename T>
+__device__ __forceinline__ float4 load_row_piece(const T* __restrict__ base, unsigned row, int ci, int ch)
 {
     // 32-bit element offset (the launcher checks rows * ci < 2^31): one v_mul_lo_u32 + one 64-bit add
-    const float* src = base + (size_t)(row * (unsigned)ci);
-    if (VEC) return *reinterpret_cast<const float4*>(src + ch);
+    const T* src = base + (size_t)(row * (unsigned)ci);
+    if (VEC) return ld4(src + ch);          // 16 bytes of f32 / 8 bytes of bf16 (ws_bf16.h)
     float4 v;
     const int last = ci - 1;
-    v.x = src[min(ch + 0, last)]; v.y = src[min(ch + 1, last)]; v.z = src[min(ch + 2, last)]; v.w = src[min(ch + 3, last)];
+    v.x = ld1(src + min(ch + 0, last)); v.y = ld1(src + min(ch + 1, last)); v.z = ld1(src + min(ch + 2, last)); v.w = ld1(src + min(ch + 3, last));
     if (ch + 0 >= ci) v.x = 0.f;
     if (ch + 1 >= ci) v.y = 0.f;
     if (ch + 2 >= ci) v.z = 0.f;
@@ -243,12 +244,12 @@ __device__ __forceinline__ void kp_list2(float ax, float ay, float az, bool aliv
 // accumulate onto the rows already written.  The index and xyz loads of the next two items are
 // software-prefetched under the current item.
 // ---------------------------------------------------------------------------------------------
-template <int K, int G, int MODE, bool DEF, bool VEC, int PW = 4>
+template <int K, int G, int MODE, bool DEF, bool VEC, int PW = 4, typename T = float>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
-    const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
+    const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci,
     const float* __restrict__ kernel_points, const float* __restrict__ deformed_kp,
-    const float* __restrict__ modulations, GeomParams g, float* __restrict__ wf,
+    const float* __restrict__ modulations, GeomParams g, T* __restrict__ wf,
     float* __restrict__ min_d2, const int32_t* __restrict__ order)
 {
     static_assert(!(DEF && MODE == 0), "deformable layers use MODE 1");
@@ -308,15 +309,15 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
                             const bool ok = beg + it + u < end;
                             e[u].x = ok ? e[u].x : 0u;
                             e[u].y = ok ? e[u].y : 0u;
-                            v[u] = x[(size_t)(e[u].x * (unsigned)ci) + chl];
+                            v[u] = ld1(x + (size_t)(e[u].x * (unsigned)ci) + chl);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) a = fmaf(__uint_as_float(e[u].y), v[u], a);
                     }
                     if (kok) {
                         if (modulations) a *= modulations[q * K + k];
-                        float* dst = wf + (q * K + k) * ci + ch;
-                        *dst = (accumulate ? *dst : 0.f) + a;
+                        T* dst = wf + (q * K + k) * ci + ch;
+                        st1(dst, (accumulate ? ld1(dst) : 0.f) + a);
                     }
                 }
             }
@@ -358,16 +359,15 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
                 }
                 if (kok) {
                     if (modulations) { const float md = modulations[q * K + k]; a.x *= md; a.y *= md; a.z *= md; a.w *= md; }
-                    float* dst = wf + (q * K + k) * ci + ch;
+                    T* dst = wf + (q * K + k) * ci + ch;
                     if (VEC) {
-                        float4* d4 = reinterpret_cast<float4*>(dst);
-                        if (accumulate) { const float4 o = *d4; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
-                        *d4 = a;
+                        if (accumulate) { const float4 o = ld4(dst); a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+                        st4(dst, a);
                     } else {
-                        if (ch + 0 < ci) dst[0] = (accumulate ? dst[0] : 0.f) + a.x;
-                        if (ch + 1 < ci) dst[1] = (accumulate ? dst[1] : 0.f) + a.y;
-                        if (ch + 2 < ci) dst[2] = (accumulate ? dst[2] : 0.f) + a.z;
-                        if (ch + 3 < ci) dst[3] = (accumulate ? dst[3] : 0.f) + a.w;
+                        if (ch + 0 < ci) st1(dst + 0, (accumulate ? ld1(dst + 0) : 0.f) + a.x);
+                        if (ch + 1 < ci) st1(dst + 1, (accumulate ? ld1(dst + 1) : 0.f) + a.y);
+                        if (ch + 2 < ci) st1(dst + 2, (accumulate ? ld1(dst + 2) : 0.f) + a.z);
+                        if (ch + 3 < ci) st1(dst + 3, (accumulate ? ld1(dst + 3) : 0.f) + a.w);
                     }
                 }
             }
@@ -470,13 +470,13 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
 // with row_e = q*K + k.  One wave per support; the flush is balanced over the S slots
 // (slot s takes entries [s*per, (s+1)*per)) and the S partial sums are combined by shuffles.
 // ---------------------------------------------------------------------------------------------
-template <int K, int G, int MODE, bool VEC>
+template <int K, int G, int MODE, bool VEC, typename T = float>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     int h, const int32_t* __restrict__ t_offsets, const int32_t* __restrict__ t_pairs,
-    const float* __restrict__ dwf, int ci, const float* __restrict__ kernel_points,
+    const T* __restrict__ dwf, int ci, const float* __restrict__ kernel_points,
     const float* __restrict__ deformed_kp, const float* __restrict__ modulations, GeomParams g,
-    float* __restrict__ dx, const int32_t* __restrict__ order)
+    T* __restrict__ dx, const int32_t* __restrict__ order)
 {
     constexpr int CC = 4 * G;
     constexpr int S = 64 / G;
@@ -575,14 +575,14 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
                 acc.w += __shfl_xor(acc.w, o, 64);
             }
             if (slot == 0) {
-                float* dst = dx + s * ci + ch;
+                T* dst = dx + s * ci + ch;
                 if (VEC) {
-                    if (chok) *reinterpret_cast<float4*>(dst) = acc;
+                    if (chok) st4(dst, acc);
                 } else {
-                    if (ch + 0 < ci) dst[0] = acc.x;
-                    if (ch + 1 < ci) dst[1] = acc.y;
-                    if (ch + 2 < ci) dst[2] = acc.z;
-                    if (ch + 3 < ci) dst[3] = acc.w;
+                    if (ch + 0 < ci) st1(dst + 0, acc.x);
+                    if (ch + 1 < ci) st1(dst + 1, acc.y);
+                    if (ch + 2 < ci) st1(dst + 2, acc.z);
+                    if (ch + 3 < ci) st1(dst + 3, acc.w);
                 }
             }
         }
@@ -599,11 +599,11 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
 // One wave per query; lane = neighbour column for the geometry, channels are looped with a wave
 // reduction of the per-(h,k) dot products through LDS-staged dwf rows.
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <int K, typename T = float>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
-    const int64_t* __restrict__ inds, int h, const float* __restrict__ x, int ci,
-    const float* __restrict__ dwf, const float* __restrict__ deformed_kp,
+    const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci,
+    const T* __restrict__ dwf, const float* __restrict__ deformed_kp,
     const float* __restrict__ modulations, const float* __restrict__ d_min_d2, GeomParams g,
     float* __restrict__ d_kp, float* __restrict__ d_mod, int vec4)
 {
@@ -638,20 +638,20 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_kernel(
                 // dot[k] = sum_c dwf[q,k,c] * x[idx,c]  (only where the weight is live)
                 float dot = 0.0f;
                 if (w[k] != 0.0f) {
-                    const float* a = dwf + (q * K + k) * ci;
-                    const float* b = x + idx * ci;
+                    const T* a = dwf + (q * K + k) * ci;
+                    const T* b = x + idx * ci;
                     if (vec4) {
                         // 16-byte pieces, four independent partial sums (the per-lane rows are L2 resident)
                         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
                         for (int cc = 0; cc < ci; cc += 4) {
-                            const float4 av = *reinterpret_cast<const float4*>(a + cc);
-                            const float4 bv = *reinterpret_cast<const float4*>(b + cc);
+                            const float4 av = ld4(a + cc);
+                            const float4 bv = ld4(b + cc);
                             s4.x = fmaf(av.x, bv.x, s4.x); s4.y = fmaf(av.y, bv.y, s4.y);
                             s4.z = fmaf(av.z, bv.z, s4.z); s4.w = fmaf(av.w, bv.w, s4.w);
                         }
                         dot = (s4.x + s4.y) + (s4.z + s4.w);
                     } else {
-                        for (int cc = 0; cc < ci; ++cc) dot = fmaf(a[cc], b[cc], dot);
+                        for (int cc = 0; cc < ci; ++cc) dot = fmaf(ld1(a + cc), ld1(b + cc), dot);
                     }
                 }
                 const float mod = modulations ? modulations[q * K + k] : 1.0f;
@@ -740,13 +740,13 @@ int check_common(const void* q_pts, int64_t nq, const void* s_pts, int64_t ns, i
 // ---------------------------------------------------------------------------------------------
 constexpr int GRID_SLAB = 192;      // incoming pairs per support (the search reports rows up to 128)
 
-template <int K, int G, int MODE, bool VEC>
+template <int K, int G, int MODE, bool VEC, typename T = float>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
     const float* __restrict__ s_pts, int64_t ns, const CloudGrid* __restrict__ grids, int nb,
     const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
-    const unsigned long long* __restrict__ key_last, float r2, const float* __restrict__ dwf, int ci,
+    const unsigned long long* __restrict__ key_last, float r2, const T* __restrict__ dwf, int ci,
     const float* __restrict__ kernel_points, const float* __restrict__ deformed_kp, const float* __restrict__ modulations,
-    GeomParams g, float* __restrict__ dx, const int32_t* __restrict__ order, int32_t* __restrict__ overflow)
+    GeomParams g, T* __restrict__ dx, const int32_t* __restrict__ order, int32_t* __restrict__ overflow)
 {
     constexpr int CC = 4 * G;
     constexpr int S = 64 / G;
@@ -930,14 +930,14 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
                 acc.w += __shfl_xor(acc.w, o, 64);
             }
             if (slot == 0) {
-                float* dst = dx + s * ci + ch;
+                T* dst = dx + s * ci + ch;
                 if (VEC) {
-                    if (chok) *reinterpret_cast<float4*>(dst) = acc;
+                    if (chok) st4(dst, acc);
                 } else {
-                    if (ch + 0 < ci) dst[0] = acc.x;
-                    if (ch + 1 < ci) dst[1] = acc.y;
-                    if (ch + 2 < ci) dst[2] = acc.z;
-                    if (ch + 3 < ci) dst[3] = acc.w;
+                    if (ch + 0 < ci) st1(dst + 0, acc.x);
+                    if (ch + 1 < ci) st1(dst + 1, acc.y);
+                    if (ch + 2 < ci) st1(dst + 2, acc.z);
+                    if (ch + 3 < ci) st1(dst + 3, acc.w);
                 }
             }
         }
@@ -945,16 +945,15 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
     }
 }
 
-}  // namespace
 
-extern "C" {
-
-int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
-                         const int64_t* inds, int32_t h, const float* x, int32_t ci,
-                         const float* kernel_points, int32_t k, const float* deformed_kp,
-                         const float* modulations, float extent, int32_t influence, int32_t aggregation,
-                         const int32_t* order, float* wf, float* min_d2, void* stream)
+template <typename T>
+int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                    const int64_t* inds, int32_t h, const T* x, int32_t ci,
+                    const float* kernel_points, int32_t k, const float* deformed_kp,
+                    const float* modulations, float extent, int32_t influence, int32_t aggregation,
+                    const int32_t* order, T* wf, float* min_d2, void* stream)
 {
+    constexpr bool F32 = sizeof(T) == 4;
     int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, influence, aggregation);
     if (rc) return rc;
     if (nq == 0) return WS_OK;
@@ -963,11 +962,14 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(nq, 4);
     WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
-    const int vec4 = (ci % 4 == 0) && aligned16(x) && aligned16(wf);
+    const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(x) && ws_row_aligned<T>(wf);
+    WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
 #define WS_FWD2(G, MODEV, DEFV, VECV)                                                                              \
-    kpconv_gather_fwd_kernel<15, G, MODEV, DEFV, VECV><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,   \
-                                                                             kernel_points, deformed_kp, modulations, \
-                                                                             g, wf, min_d2, order)
+    do {                                                                                                           \
+        if constexpr (F32 || VECV)                                                                                 \
+            kpconv_gather_fwd_kernel<15, G, MODEV, DEFV, VECV, 4, T><<<grid, 256, 0, st>>>(                        \
+                q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points, deformed_kp, modulations, g, wf, min_d2, order); \
+    } while (0)
 #define WS_FWD(G)                                                                                   \
     do {                                                                                            \
         if (deformed_kp) { if (vec4) WS_FWD2(G, 1, true, true); else WS_FWD2(G, 1, true, false); }  \
@@ -978,9 +980,11 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
     if (ci <= 4 && !vec4) {
         // narrow rows that are not float4 (the 3-channel input layer): 4-byte pieces, 16 slots of 4 lanes
 #define WS_FWDN(MODEV, DEFV)                                                                                          \
-    kpconv_gather_fwd_kernel<15, 4, MODEV, DEFV, false, 1><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci,  \
-                                                                                 kernel_points, deformed_kp, modulations, \
-                                                                                 g, wf, min_d2, order)
+    do {                                                                                                              \
+        if constexpr (F32)                                                                                            \
+            kpconv_gather_fwd_kernel<15, 4, MODEV, DEFV, false, 1, T><<<grid, 256, 0, st>>>(                          \
+                q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points, deformed_kp, modulations, g, wf, min_d2, order);  \
+    } while (0)
         if (deformed_kp) WS_FWDN(1, true);
         else if (fast) WS_FWDN(0, false);
         else WS_FWDN(1, false);
@@ -997,12 +1001,14 @@ int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int
     return WS_OK;
 }
 
-int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
-                           const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
-                           const float* dwf, int32_t ci, const float* kernel_points, int32_t k,
-                           const float* deformed_kp, const float* modulations, float extent,
-                           int32_t influence, int32_t aggregation, const int32_t* order, float* dx, void* stream)
+template <typename T>
+int gather_bwd_x_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                      const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
+                      const T* dwf, int32_t ci, const float* kernel_points, int32_t k,
+                      const float* deformed_kp, const float* modulations, float extent,
+                      int32_t influence, int32_t aggregation, const int32_t* order, T* dx, void* stream)
 {
+    constexpr bool F32 = sizeof(T) == 4;
     (void)inds;
     int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, influence, aggregation);
     if (rc) return rc;
@@ -1013,11 +1019,14 @@ int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, i
     GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(ns, 4);
-    const int vec4 = (ci % 4 == 0) && aligned16(dwf) && aligned16(dx);
+    const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
+    WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
 #define WS_BWD2(G, MODEV, VECV)                                                                                       \
-    kpconv_gather_bwd_x_kernel<15, G, MODEV, VECV><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs,  \
-                                                                         dwf, ci, kernel_points, deformed_kp,          \
-                                                                         modulations, g, dx, order)
+    do {                                                                                                              \
+        if constexpr (F32 || VECV)                                                                                    \
+            kpconv_gather_bwd_x_kernel<15, G, MODEV, VECV, T><<<grid, 256, 0, st>>>(                                   \
+                q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, dwf, ci, kernel_points, deformed_kp, modulations, g, dx, order); \
+    } while (0)
 #define WS_BWD(G)                                                                       \
     do {                                                                                \
         if (fast) { if (vec4) WS_BWD2(G, 0, true); else WS_BWD2(G, 0, false); }          \
@@ -1035,12 +1044,13 @@ int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, i
     return WS_OK;
 }
 
-int ws_kpconv_gather_bwd_geom(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
-                              const int64_t* inds, int32_t h, const float* x, int32_t ci, const float* dwf,
-                              const float* kernel_points, int32_t k, const float* deformed_kp,
-                              const float* modulations, const float* d_min_d2, float extent,
-                              int32_t influence, int32_t aggregation, float* d_deformed_kp,
-                              float* d_modulations, void* stream)
+template <typename T>
+int gather_bwd_geom_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                         const int64_t* inds, int32_t h, const T* x, int32_t ci, const T* dwf,
+                         const float* kernel_points, int32_t k, const float* deformed_kp,
+                         const float* modulations, const float* d_min_d2, float extent,
+                         int32_t influence, int32_t aggregation, float* d_deformed_kp,
+                         float* d_modulations, void* stream)
 {
     (void)kernel_points;
     int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, influence, aggregation);
@@ -1049,20 +1059,22 @@ int ws_kpconv_gather_bwd_geom(const float* q_pts, int64_t nq, const float* s_pts
     WS_REQUIRE(inds && x && dwf && deformed_kp && d_deformed_kp, "NULL argument");
     GeomParams g{extent, influence, aggregation, 1};
     hipStream_t st = (hipStream_t)stream;
-    kpconv_gather_bwd_geom_kernel<15><<<ws_grid(nq, 4), 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf,
-                                                                       deformed_kp, modulations, d_min_d2, g,
-                                                                       d_deformed_kp, d_modulations,
-                                                                       (ci % 4 == 0) && aligned16(x) && aligned16(dwf));
+    kpconv_gather_bwd_geom_kernel<15, T><<<ws_grid(nq, 4), 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf,
+                                                                          deformed_kp, modulations, d_min_d2, g,
+                                                                          d_deformed_kp, d_modulations,
+                                                                          (ci % 4 == 0) && ws_row_aligned<T>(x) && ws_row_aligned<T>(dwf));
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
 
-int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
-                                const uint64_t* key_last, float radius, const float* dwf, int32_t ci,
-                                const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
-                                float extent, int32_t influence, int32_t aggregation, const int32_t* order, float* dx,
-                                int32_t* overflow, void* stream)
+template <typename T>
+int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                           const uint64_t* key_last, float radius, const T* dwf, int32_t ci,
+                           const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                           float extent, int32_t influence, int32_t aggregation, const int32_t* order, T* dx,
+                           int32_t* overflow, void* stream)
 {
+    constexpr bool F32 = sizeof(T) == 4;
     int rc = check_common(s_pts, ns, s_pts, ns, 1, ci, k, extent, influence, aggregation);
     if (rc) return rc;
     if (ns == 0) return WS_OK;
@@ -1078,11 +1090,14 @@ int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid
     const float r2 = radius * radius;                       // neighbors.cpp:226, as in the search
     const unsigned long long* kl = reinterpret_cast<const unsigned long long*>(key_last);
     const int grid = ws_grid(ns, 4);
-    const int vec4 = (ci % 4 == 0) && aligned16(dwf) && aligned16(dx);
+    const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
+    WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
 #define WS_BWDG2(G, MODEV, VECV)                                                                                     \
-    kpconv_gather_bwd_x_grid_kernel<15, G, MODEV, VECV><<<grid, 256, 0, st>>>(s_pts, ns, grids, nb, cell_start, sorted, kl, r2, \
-                                                                              dwf, ci, kernel_points, deformed_kp,    \
-                                                                              modulations, g, dx, order, overflow)
+    do {                                                                                                             \
+        if constexpr (F32 || VECV)                                                                                   \
+            kpconv_gather_bwd_x_grid_kernel<15, G, MODEV, VECV, T><<<grid, 256, 0, st>>>(                             \
+                s_pts, ns, grids, nb, cell_start, sorted, kl, r2, dwf, ci, kernel_points, deformed_kp, modulations, g, dx, order, overflow); \
+    } while (0)
 #define WS_BWDG(G)                                                                      \
     do {                                                                                \
         if (fast) { if (vec4) WS_BWDG2(G, 0, true); else WS_BWDG2(G, 0, false); }        \
@@ -1098,6 +1113,96 @@ int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid
 #undef WS_BWDG
     WS_LAUNCH_CHECK();
     return WS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                         const int64_t* inds, int32_t h, const float* x, int32_t ci,
+                         const float* kernel_points, int32_t k, const float* deformed_kp,
+                         const float* modulations, float extent, int32_t influence, int32_t aggregation,
+                         const int32_t* order, float* wf, float* min_d2, void* stream)
+{
+    return gather_fwd_impl<float>(q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points, k, deformed_kp, modulations, extent,
+                                  influence, aggregation, order, wf, min_d2, stream);
+}
+
+int ws_kpconv_gather_fwd_bf16(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                              const int64_t* inds, int32_t h, const uint16_t* x, int32_t ci,
+                              const float* kernel_points, int32_t k, const float* deformed_kp,
+                              const float* modulations, float extent, int32_t influence, int32_t aggregation,
+                              const int32_t* order, uint16_t* wf, float* min_d2, void* stream)
+{
+    return gather_fwd_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, reinterpret_cast<const bf16_t*>(x), ci, kernel_points, k,
+                                   deformed_kp, modulations, extent, influence, aggregation, order,
+                                   reinterpret_cast<bf16_t*>(wf), min_d2, stream);
+}
+
+int ws_kpconv_gather_bwd_x(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                           const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
+                           const float* dwf, int32_t ci, const float* kernel_points, int32_t k,
+                           const float* deformed_kp, const float* modulations, float extent,
+                           int32_t influence, int32_t aggregation, const int32_t* order, float* dx, void* stream)
+{
+    return gather_bwd_x_impl<float>(q_pts, nq, s_pts, ns, inds, h, t_offsets, t_pairs, dwf, ci, kernel_points, k, deformed_kp,
+                                    modulations, extent, influence, aggregation, order, dx, stream);
+}
+
+int ws_kpconv_gather_bwd_x_bf16(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                                const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
+                                const uint16_t* dwf, int32_t ci, const float* kernel_points, int32_t k,
+                                const float* deformed_kp, const float* modulations, float extent,
+                                int32_t influence, int32_t aggregation, const int32_t* order, uint16_t* dx, void* stream)
+{
+    return gather_bwd_x_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, t_offsets, t_pairs, reinterpret_cast<const bf16_t*>(dwf), ci,
+                                     kernel_points, k, deformed_kp, modulations, extent, influence, aggregation, order,
+                                     reinterpret_cast<bf16_t*>(dx), stream);
+}
+
+int ws_kpconv_gather_bwd_geom(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                              const int64_t* inds, int32_t h, const float* x, int32_t ci, const float* dwf,
+                              const float* kernel_points, int32_t k, const float* deformed_kp,
+                              const float* modulations, const float* d_min_d2, float extent,
+                              int32_t influence, int32_t aggregation, float* d_deformed_kp,
+                              float* d_modulations, void* stream)
+{
+    return gather_bwd_geom_impl<float>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf, kernel_points, k, deformed_kp, modulations,
+                                       d_min_d2, extent, influence, aggregation, d_deformed_kp, d_modulations, stream);
+}
+
+int ws_kpconv_gather_bwd_geom_bf16(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                                   const int64_t* inds, int32_t h, const uint16_t* x, int32_t ci, const uint16_t* dwf,
+                                   const float* kernel_points, int32_t k, const float* deformed_kp,
+                                   const float* modulations, const float* d_min_d2, float extent,
+                                   int32_t influence, int32_t aggregation, float* d_deformed_kp,
+                                   float* d_modulations, void* stream)
+{
+    return gather_bwd_geom_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, reinterpret_cast<const bf16_t*>(x), ci,
+                                        reinterpret_cast<const bf16_t*>(dwf), kernel_points, k, deformed_kp, modulations,
+                                        d_min_d2, extent, influence, aggregation, d_deformed_kp, d_modulations, stream);
+}
+
+int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                const uint64_t* key_last, float radius, const float* dwf, int32_t ci,
+                                const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                                float extent, int32_t influence, int32_t aggregation, const int32_t* order, float* dx,
+                                int32_t* overflow, void* stream)
+{
+    return gather_bwd_x_grid_impl<float>(s_pts, ns, grid_blob, nb, cells, key_last, radius, dwf, ci, kernel_points, k, deformed_kp,
+                                         modulations, extent, influence, aggregation, order, dx, overflow, stream);
+}
+
+int ws_kpconv_gather_bwd_x_grid_bf16(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                     const uint64_t* key_last, float radius, const uint16_t* dwf, int32_t ci,
+                                     const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                                     float extent, int32_t influence, int32_t aggregation, const int32_t* order, uint16_t* dx,
+                                     int32_t* overflow, void* stream)
+{
+    return gather_bwd_x_grid_impl<bf16_t>(s_pts, ns, grid_blob, nb, cells, key_last, radius, reinterpret_cast<const bf16_t*>(dwf), ci,
+                                          kernel_points, k, deformed_kp, modulations, extent, influence, aggregation, order,
+                                          reinterpret_cast<bf16_t*>(dx), overflow, stream);
 }
 
 }  // extern "C"

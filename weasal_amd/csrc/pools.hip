@@ -3,6 +3,7 @@
 // access is a coalesced row segment; the backward forms gather through the transposed table
 // (csr.hip) instead of the reference's scatter_add.
 #include "ws_common.h"
+#include "ws_bf16.h"
 
 namespace {
 
@@ -12,10 +13,10 @@ bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; 
 // VEC path (c % 4 == 0, 16-byte aligned rows): G = c/4 lanes (capped at 64) cover one row with
 // float4 pieces, 64/G query rows per wave, the neighbour loop unrolled by 4 so that four row
 // gathers are in flight per lane; shadow columns read nothing (zero row, blocks.py:104).
-template <int G>
-__global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const float* __restrict__ x, int64_t ns, int c,
+template <int G, typename T>
+__global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restrict__ x, int64_t ns, int c,
                                                                 const int64_t* __restrict__ inds, int64_t nq, int h,
-                                                                float* __restrict__ out, int32_t* __restrict__ arg)
+                                                                T* __restrict__ out, int32_t* __restrict__ arg)
 {
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const float* __re
                     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int col = h0 + u;
                     int64_t s = (ok && col < h) ? inds[q * h + col] : -1;
-                    if (s >= 0 && s < ns) v[u] = *reinterpret_cast<const float4*>(x + s * c + ch);
+                    if (s >= 0 && s < ns) v[u] = ld4(x + s * c + ch);
                     else if (col >= h) v[u] = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
                 }
 #pragma unroll
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const float* __re
                 }
             }
             if (ok) {
-                *reinterpret_cast<float4*>(out + q * c + ch) = best;
+                st4(out + q * c + ch, best);
                 if (arg) *reinterpret_cast<int4*>(arg + q * c + ch) = make_int4(bi[0], bi[1], bi[2], bi[3]);
             }
         }
@@ -57,9 +58,10 @@ __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const float* __re
 }
 
 // generic path: one wave per query row; lanes stride over channels
-__global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float* __restrict__ x, int64_t ns, int c,
+template <typename T>
+__global__ __launch_bounds__(256) void max_pool_fwd_kernel(const T* __restrict__ x, int64_t ns, int c,
                                                             const int64_t* __restrict__ inds, int64_t nq, int h,
-                                                            float* __restrict__ out, int32_t* __restrict__ arg)
+                                                            T* __restrict__ out, int32_t* __restrict__ arg)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
@@ -70,11 +72,11 @@ __global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float* __restri
             for (int j = 0; j < h; ++j) {
                 const int64_t s = inds[q * h + j];           // wave-uniform
                 float v = 0.0f;                               // shadow row = zeros (blocks.py:104)
-                if (s >= 0 && s < ns && ch < c) v = x[s * c + ch];
+                if (s >= 0 && s < ns && ch < c) v = ld1(x + s * c + ch);
                 if (v > best) { best = v; bi = j; }           // first maximum wins
             }
             if (ch < c) {
-                out[q * c + ch] = best;
+                st1(out + q * c + ch, best);
                 if (arg) arg[q * c + ch] = bi;
             }
         }
@@ -82,11 +84,11 @@ __global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float* __restri
 }
 
 // backward, VEC path: G lanes x float4 per support row, 64/G supports per wave
-template <int G>
-__global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg,
+template <int G, typename T>
+__global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restrict__ dy, const int32_t* __restrict__ arg,
                                                                 int h, int c, const int32_t* __restrict__ t_offsets,
                                                                 const int32_t* __restrict__ t_pairs, int64_t ns,
-                                                                float* __restrict__ dx)
+                                                                T* __restrict__ dx)
 {
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -105,22 +107,23 @@ __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const float* __re
                 const int pair = t_pairs[p];
                 const int q = pair / h, col = pair - q * h;
                 const int4 a = *reinterpret_cast<const int4*>(arg + (int64_t)q * c + ch);
-                const float4 g = *reinterpret_cast<const float4*>(dy + (int64_t)q * c + ch);
+                const float4 g = ld4(dy + (int64_t)q * c + ch);
                 if (a.x == col) acc.x += g.x;
                 if (a.y == col) acc.y += g.y;
                 if (a.z == col) acc.z += g.z;
                 if (a.w == col) acc.w += g.w;
             }
-            *reinterpret_cast<float4*>(dx + s * c + ch) = acc;
+            st4(dx + s * c + ch, acc);
         }
     }
 }
 
 // one wave per support row
-__global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg,
+template <typename T>
+__global__ __launch_bounds__(256) void max_pool_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ arg,
                                                             int h, int c, const int32_t* __restrict__ t_offsets,
                                                             const int32_t* __restrict__ t_pairs, int64_t ns,
-                                                            float* __restrict__ dx)
+                                                            T* __restrict__ dx)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < ns; s += (int64_t)gridDim.x * 4) {
@@ -132,30 +135,32 @@ __global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float* __restri
                 for (int p = beg; p < end; ++p) {
                     const int pair = t_pairs[p];
                     const int q = pair / h, col = pair - q * h;
-                    if (arg[(int64_t)q * c + ch] == col) acc += dy[(int64_t)q * c + ch];
+                    if (arg[(int64_t)q * c + ch] == col) acc += ld1(dy + (int64_t)q * c + ch);
                 }
-                dx[s * c + ch] = acc;
+                st1(dx + s * c + ch, acc);
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void closest_pool_fwd_kernel(const float* __restrict__ x, int64_t ns, int c,
+template <typename T>
+__global__ __launch_bounds__(256) void closest_pool_fwd_kernel(const T* __restrict__ x, int64_t ns, int c,
                                                                 const int64_t* __restrict__ inds, int64_t nq, int h,
-                                                                float* __restrict__ out)
+                                                                T* __restrict__ out)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
         const int64_t s = inds[q * h];
         const bool real = s >= 0 && s < ns;
-        for (int ch = lane; ch < c; ch += 64) out[q * c + ch] = real ? x[s * c + ch] : 0.0f;
+        for (int ch = lane; ch < c; ch += 64) st1(out + q * c + ch, real ? ld1(x + s * c + ch) : 0.0f);
     }
 }
 
-__global__ __launch_bounds__(256) void closest_pool_bwd_kernel(const float* __restrict__ dy, int h, int c,
+template <typename T>
+__global__ __launch_bounds__(256) void closest_pool_bwd_kernel(const T* __restrict__ dy, int h, int c,
                                                                 const int32_t* __restrict__ t_offsets,
                                                                 const int32_t* __restrict__ t_pairs, int64_t ns,
-                                                                float* __restrict__ dx)
+                                                                T* __restrict__ dx)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < ns; s += (int64_t)gridDim.x * 4) {
@@ -167,12 +172,74 @@ __global__ __launch_bounds__(256) void closest_pool_bwd_kernel(const float* __re
                 for (int p = beg; p < end; ++p) {
                     const int pair = t_pairs[p];
                     const int q = pair / h;
-                    if (pair - q * h == 0) acc += dy[(int64_t)q * c + ch];
+                    if (pair - q * h == 0) acc += ld1(dy + (int64_t)q * c + ch);
                 }
-                dx[s * c + ch] = acc;
+                st1(dx + s * c + ch, acc);
             }
         }
     }
+}
+
+
+template <typename T>
+int max_pool_fwd_impl(const T* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                      T* out, int32_t* arg, void* stream)
+{
+    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
+    if (nq == 0) return WS_OK;
+    WS_REQUIRE(inds && out && (ns == 0 || x), "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && ws_row_aligned<T>(x) && ws_row_aligned<T>(out) && (!arg || al16p(arg));
+    if (vec && c <= 16) max_pool_fwd_vec_kernel<4, T><<<ws_grid(ws_ceil_div(nq, 16), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (vec && c <= 32) max_pool_fwd_vec_kernel<8, T><<<ws_grid(ws_ceil_div(nq, 8), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (vec && c <= 64) max_pool_fwd_vec_kernel<16, T><<<ws_grid(ws_ceil_div(nq, 4), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (vec && c <= 128) max_pool_fwd_vec_kernel<32, T><<<ws_grid(ws_ceil_div(nq, 2), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (vec) max_pool_fwd_vec_kernel<64, T><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else max_pool_fwd_kernel<T><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+template <typename T>
+int max_pool_bwd_impl(const T* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c,
+                      const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns, T* dx, void* stream)
+{
+    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
+    if (ns == 0) return WS_OK;
+    WS_REQUIRE(t_offsets && dx && (nq == 0 || (dy && arg && t_pairs)), "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && ws_row_aligned<T>(dy) && ws_row_aligned<T>(dx) && al16p(arg);
+    if (vec && c <= 32) max_pool_bwd_vec_kernel<8, T><<<ws_grid(ws_ceil_div(ns, 8), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else if (vec && c <= 64) max_pool_bwd_vec_kernel<16, T><<<ws_grid(ws_ceil_div(ns, 4), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else if (vec && c <= 128) max_pool_bwd_vec_kernel<32, T><<<ws_grid(ws_ceil_div(ns, 2), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else if (vec) max_pool_bwd_vec_kernel<64, T><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else max_pool_bwd_kernel<T><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+template <typename T>
+int closest_pool_fwd_impl(const T* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                          T* out, void* stream)
+{
+    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
+    if (nq == 0) return WS_OK;
+    WS_REQUIRE(inds && out && (ns == 0 || x), "NULL argument");
+    closest_pool_fwd_kernel<T><<<ws_grid(nq, 4), 256, 0, (hipStream_t)stream>>>(x, ns, c, inds, nq, h, out);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+template <typename T>
+int closest_pool_bwd_impl(const T* dy, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                          const int32_t* t_pairs, int64_t ns, T* dx, void* stream)
+{
+    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
+    if (ns == 0) return WS_OK;
+    WS_REQUIRE(t_offsets && dx && (nq == 0 || (dy && t_pairs)), "NULL argument");
+    closest_pool_bwd_kernel<T><<<ws_grid(ns, 4), 256, 0, (hipStream_t)stream>>>(dy, h, c, t_offsets, t_pairs, ns, dx);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
 }
 
 }  // namespace
@@ -182,58 +249,52 @@ extern "C" {
 int ws_max_pool_fwd(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
                     float* out, int32_t* arg, void* stream)
 {
-    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
-    if (nq == 0) return WS_OK;
-    WS_REQUIRE(inds && out && (ns == 0 || x), "NULL argument");
-    hipStream_t st = (hipStream_t)stream;
-    const bool vec = (c % 4 == 0) && al16p(x) && al16p(out) && (!arg || al16p(arg));
-    if (vec && c <= 16) max_pool_fwd_vec_kernel<4><<<ws_grid(ws_ceil_div(nq, 16), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (vec && c <= 32) max_pool_fwd_vec_kernel<8><<<ws_grid(ws_ceil_div(nq, 8), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (vec && c <= 64) max_pool_fwd_vec_kernel<16><<<ws_grid(ws_ceil_div(nq, 4), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (vec && c <= 128) max_pool_fwd_vec_kernel<32><<<ws_grid(ws_ceil_div(nq, 2), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (vec) max_pool_fwd_vec_kernel<64><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else max_pool_fwd_kernel<<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    WS_LAUNCH_CHECK();
-    return WS_OK;
+    return max_pool_fwd_impl<float>(x, ns, c, inds, nq, h, out, arg, stream);
 }
 
 int ws_max_pool_bwd(const float* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c,
                     const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns, float* dx, void* stream)
 {
-    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
-    if (ns == 0) return WS_OK;
-    WS_REQUIRE(t_offsets && dx && (nq == 0 || (dy && arg && t_pairs)), "NULL argument");
-    hipStream_t st = (hipStream_t)stream;
-    const bool vec = (c % 4 == 0) && al16p(dy) && al16p(dx) && al16p(arg);
-    if (vec && c <= 32) max_pool_bwd_vec_kernel<8><<<ws_grid(ws_ceil_div(ns, 8), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else if (vec && c <= 64) max_pool_bwd_vec_kernel<16><<<ws_grid(ws_ceil_div(ns, 4), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else if (vec && c <= 128) max_pool_bwd_vec_kernel<32><<<ws_grid(ws_ceil_div(ns, 2), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else if (vec) max_pool_bwd_vec_kernel<64><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else max_pool_bwd_kernel<<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    WS_LAUNCH_CHECK();
-    return WS_OK;
+    return max_pool_bwd_impl<float>(dy, arg, nq, h, c, t_offsets, t_pairs, ns, dx, stream);
 }
 
 int ws_closest_pool_fwd(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
                         float* out, void* stream)
 {
-    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
-    if (nq == 0) return WS_OK;
-    WS_REQUIRE(inds && out && (ns == 0 || x), "NULL argument");
-    closest_pool_fwd_kernel<<<ws_grid(nq, 4), 256, 0, (hipStream_t)stream>>>(x, ns, c, inds, nq, h, out);
-    WS_LAUNCH_CHECK();
-    return WS_OK;
+    return closest_pool_fwd_impl<float>(x, ns, c, inds, nq, h, out, stream);
 }
 
 int ws_closest_pool_bwd(const float* dy, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
                         const int32_t* t_pairs, int64_t ns, float* dx, void* stream)
 {
-    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
-    if (ns == 0) return WS_OK;
-    WS_REQUIRE(t_offsets && dx && (nq == 0 || (dy && t_pairs)), "NULL argument");
-    closest_pool_bwd_kernel<<<ws_grid(ns, 4), 256, 0, (hipStream_t)stream>>>(dy, h, c, t_offsets, t_pairs, ns, dx);
-    WS_LAUNCH_CHECK();
-    return WS_OK;
+    return closest_pool_bwd_impl<float>(dy, nq, h, c, t_offsets, t_pairs, ns, dx, stream);
+}
+
+// bf16 feature rows (BASELINE config 5): same kernels, 8-byte row pieces
+int ws_max_pool_fwd_bf16(const uint16_t* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                         uint16_t* out, int32_t* arg, void* stream)
+{
+    return max_pool_fwd_impl<bf16_t>(reinterpret_cast<const bf16_t*>(x), ns, c, inds, nq, h, reinterpret_cast<bf16_t*>(out), arg, stream);
+}
+
+int ws_max_pool_bwd_bf16(const uint16_t* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c,
+                         const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns, uint16_t* dx, void* stream)
+{
+    return max_pool_bwd_impl<bf16_t>(reinterpret_cast<const bf16_t*>(dy), arg, nq, h, c, t_offsets, t_pairs, ns,
+                                     reinterpret_cast<bf16_t*>(dx), stream);
+}
+
+int ws_closest_pool_fwd_bf16(const uint16_t* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                             uint16_t* out, void* stream)
+{
+    return closest_pool_fwd_impl<bf16_t>(reinterpret_cast<const bf16_t*>(x), ns, c, inds, nq, h, reinterpret_cast<bf16_t*>(out), stream);
+}
+
+int ws_closest_pool_bwd_bf16(const uint16_t* dy, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                             const int32_t* t_pairs, int64_t ns, uint16_t* dx, void* stream)
+{
+    return closest_pool_bwd_impl<bf16_t>(reinterpret_cast<const bf16_t*>(dy), nq, h, c, t_offsets, t_pairs, ns,
+                                         reinterpret_cast<bf16_t*>(dx), stream);
 }
 
 }  // extern "C"

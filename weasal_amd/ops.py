@@ -177,12 +177,16 @@ class _KPConvGather(torch.autograd.Function):
         nq, h = inds.shape
         ns, ci = x.shape
         k = kernel_points.shape[0]
-        wf = torch.empty((nq, k, ci), dtype=torch.float32, device=x.device)
+        bf = x.dtype == torch.bfloat16          # bf16 feature rows (BASELINE config 5): same kernels, 8-byte row pieces
+        if not bf and x.dtype != torch.float32:
+            raise _lib.WeasalHipError("kpconv_gather: features must be float32 or bfloat16 (got %s)" % x.dtype)
+        wf = torch.empty((nq, k, ci), dtype=x.dtype, device=x.device)
         min_d2 = torch.empty((nq, k), dtype=torch.float32, device=x.device) if want_min_d2 else None
-        dkp = deformed_kp.contiguous() if deformed_kp is not None else None
-        mod = modulations.contiguous() if modulations is not None else None
+        dkp = deformed_kp.float().contiguous() if deformed_kp is not None else None
+        mod = modulations.float().contiguous() if modulations is not None else None
         tok = _tbegin("kpconv_gather_fwd", nq, h, ci)
-        check(lib.ws_kpconv_gather_fwd(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci,
+        fwd = lib.ws_kpconv_gather_fwd_bf16 if bf else lib.ws_kpconv_gather_fwd
+        check(fwd(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci,
                                        ptr(kernel_points), k, ptr(dkp), ptr(mod), float(extent),
                                        influence, aggregation, ptr(_order_for(q_pts)), ptr(wf), ptr(min_d2),
                                        current_stream()))
@@ -199,7 +203,11 @@ class _KPConvGather(torch.autograd.Function):
         nq, h = inds.shape
         ns, ci = x.shape
         k = kernel_points.shape[0]
-        dwf = dwf.contiguous()
+        bf = x.dtype == torch.bfloat16
+        dwf = dwf.contiguous() if dwf.dtype == x.dtype else dwf.to(x.dtype).contiguous()
+        f_grid = lib.ws_kpconv_gather_bwd_x_grid_bf16 if bf else lib.ws_kpconv_gather_bwd_x_grid
+        f_tab = lib.ws_kpconv_gather_bwd_x_bf16 if bf else lib.ws_kpconv_gather_bwd_x
+        f_geom = lib.ws_kpconv_gather_bwd_geom_bf16 if bf else lib.ws_kpconv_gather_bwd_geom
         dx = d_dkp = d_mod = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -207,14 +215,14 @@ class _KPConvGather(torch.autograd.Function):
             tok = _tbegin("kpconv_gather_bwd_x", nq, h, ci)
             if grid is not None and grid.ns == ns:
                 # self-query layer: incoming pairs re-derived from the search grid, no transposed table
-                check(lib.ws_kpconv_gather_bwd_x_grid(ptr(s_pts), ns, ptr(grid.blob), grid.nb, grid.cells,
+                check(f_grid(ptr(s_pts), ns, ptr(grid.blob), grid.nb, grid.cells,
                                                       ptr(grid.key_last), grid.radius, ptr(dwf), ci, ptr(kernel_points), k,
                                                       ptr(dkp), ptr(mod), extent, influence, aggregation,
                                                       ptr(_order_for(s_pts)), ptr(dx), ptr(grid.overflow),
                                                       current_stream()))
             else:
                 table = transposed_table(inds, ns)
-                check(lib.ws_kpconv_gather_bwd_x(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(table.offsets),
+                check(f_tab(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(table.offsets),
                                                  ptr(table.pairs), ptr(dwf), ci, ptr(kernel_points), k, ptr(dkp),
                                                  ptr(mod), extent, influence, aggregation, ptr(_order_for(s_pts)),
                                                  ptr(dx), current_stream()))
@@ -223,7 +231,7 @@ class _KPConvGather(torch.autograd.Function):
             d_dkp = torch.empty_like(dkp)
             d_mod = torch.empty_like(mod) if mod is not None else None
             dmin = d_min_d2.contiguous() if d_min_d2 is not None else None
-            check(lib.ws_kpconv_gather_bwd_geom(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(dwf),
+            check(f_geom(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(dwf),
                                                 ptr(kernel_points), k, ptr(dkp), ptr(mod), ptr(dmin), extent,
                                                 influence, aggregation, ptr(d_dkp), ptr(d_mod), current_stream()))
         return dx, d_dkp, d_mod, None, None, None, None, None, None, None, None
@@ -309,6 +317,116 @@ class _MatmulXB(torch.autograd.Function):
         return dx, db
 
 
+# ---- bf16 rows (BASELINE config 5): X, the small matrix and Y bf16 in HBM, fp32 accumulate on the bf16 MFMA --------------
+def _bf16_ok(x, k):
+    return x.dtype == torch.bfloat16 and k % 32 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+
+
+def _bt16(b):
+    """the small matrix b [K,N] (fp32 master, any strides) as contiguous bf16 [N,K]: one strided copy-cast kernel"""
+    out = torch.empty((b.shape[1], b.shape[0]), dtype=torch.bfloat16, device=b.device)
+    out.copy_(b.t())
+    return out
+
+
+def _xbt16(lib, x, bt, bias, residual, slope, out_f32):
+    """act(x @ bt^T + bias + residual): x [M,K] bf16, bt [N,K] bf16 -> [M,N] bf16 (or f32)"""
+    m, k = x.shape
+    n = bt.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    act, sl = (0, 0.0) if slope is None else (1, float(slope))
+    check(lib.ws_gemm_xbt_bf16(ptr(x), m, k, x.stride(0), ptr(bt), n, bt.stride(0), ptr(bias), ptr(residual),
+                               residual.stride(0) if residual is not None else 0, act, sl, ptr(y), n, 1 if out_f32 else 0,
+                               current_stream()))
+    return y
+
+
+def _xty16(lib, x, dz):
+    """x^T @ dz -> f32 [K,N] (the master gradient); x, dz bf16 rows"""
+    m, k = x.shape
+    n = dz.shape[1]
+    db = torch.empty((k, n), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(max(lib.ws_gemm_xty_scratch_bytes(m, k, n), 16), dtype=torch.uint8, device=x.device)
+    check(lib.ws_gemm_xty_bf16(ptr(x), m, k, x.stride(0), ptr(dz), n, dz.stride(0), ptr(db), ptr(scratch), current_stream()))
+    return db
+
+
+class _MatmulEpilogueBF16(torch.autograd.Function):
+    """y = act(x @ b + bias + residual) with bf16 rows: x [M,K] bf16, b [K,N] the fp32 master (cast to bf16 here),
+    bias f32, residual bf16, y bf16 -- or f32 (out_f32: logits, deformable offsets).  Backward: dz = dy*act'(y) (bf16) and
+    the f32 bias gradient in one pass, dx = dz @ b^T on the bf16 MFMA, dW = x^T dz in fp32 (exact products).
+    Shapes the bf16 kernels do not take (contraction depth not a multiple of 32: the 9 logits' dx) go through the f32
+    kernels on widened operands."""
+
+    @staticmethod
+    def forward(ctx, x, b, bias, residual, slope, out_f32):
+        lib = _lib.lib()
+        m, k = x.shape
+        n = b.shape[1]
+        xc = x if (x.stride(1) == 1 and x.stride(0) >= k) else x.contiguous()
+        rc = None
+        if residual is not None:
+            rc = residual if residual.dtype == torch.bfloat16 else residual.to(torch.bfloat16)
+            rc = rc if (rc.stride(1) == 1 and rc.stride(0) >= n) else rc.contiguous()
+        biasc = bias.float().contiguous() if bias is not None else None
+        if _bf16_ok(xc, k):
+            y = _xbt16(lib, xc, _bt16(b), biasc, rc, slope, out_f32)
+        else:
+            y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+            _xb_launch(lib, xc.float(), m, k, b.float().contiguous(), n, biasc, rc.float() if rc is not None else None, slope, y)
+            y = y if out_f32 else y.to(torch.bfloat16)
+        ctx.slope = slope
+        ctx.has = (bias is not None, residual is not None)
+        ctx.save_for_backward(xc, b, y if slope is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.lib()
+        x, b, y = ctx.saved_tensors
+        m, k = x.shape
+        n = b.shape[1]
+        dy = _rowmajor(dy)
+        want_bias = ctx.has[0] and ctx.needs_input_grad[2]
+        if n % 4 == 0:
+            dz, dbias = _act_bwd_colsum16(lib, dy, y, ctx.slope, want_bias)          # bf16 rows
+        else:                                                                           # the 9 logits: f32 rows
+            dz, dbias = _act_bwd_colsum(dy.float(), y.float() if y is not None else None, ctx.slope, want_bias)
+        dx = db = dres = None
+        if ctx.needs_input_grad[0]:
+            if dz.dtype == torch.bfloat16 and _bf16_ok(dz, n):
+                dx = _xbt16(lib, dz, b.to(torch.bfloat16).contiguous() if b.is_contiguous() else _bt16(b.t()), None, None, None, False)
+            else:
+                dx = _gemm_xb(dz.float().contiguous(), b.t().float().contiguous()).to(torch.bfloat16)
+        dz16 = dz if dz.dtype == torch.bfloat16 else dz.to(torch.bfloat16)
+        if ctx.needs_input_grad[1]:
+            db = _xty16(lib, x, dz16)
+        if ctx.has[1] and ctx.needs_input_grad[3]:
+            dres = dz16
+        return dx, db, dbias, dres, None, None
+
+
+def _act_bwd_colsum16(lib, dy, y, slope, want_colsum):
+    """bf16 form of _act_bwd_colsum: dy bf16 or f32, y bf16 (None: identity) -> (dz bf16, f32 column sums or None)"""
+    m, n = dy.shape
+    f32 = dy.dtype == torch.float32
+    if y is None and not want_colsum and not f32:
+        return dy, None
+    need_dz = y is not None or f32
+    dz = torch.empty((m, n), dtype=torch.bfloat16, device=dy.device) if need_dz else None
+    colsum = scratch = None
+    if want_colsum:
+        colsum = torch.empty((n,), dtype=torch.float32, device=dy.device)
+        scratch = torch.empty(max(lib.ws_act_bwd_colsum_bf16_scratch_bytes(m, n), 16), dtype=torch.uint8, device=dy.device)
+    yb = None
+    if y is not None:
+        yb = y if y.dtype == torch.bfloat16 else y.to(torch.bfloat16)      # only the sign is used
+    check(lib.ws_act_bwd_colsum_bf16(ptr(dy), 1 if f32 else 0, m, n, dy.stride(0), ptr(yb), yb.stride(0) if yb is not None else 0,
+                                     0.0 if slope is None else float(slope), ptr(dz), n if dz is not None else 0, ptr(colsum),
+                                     ptr(scratch), current_stream()))
+    return (dz if need_dz else dy), colsum
+
+
 def _rowmajor(t):
     return t if (t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous()
 
@@ -367,10 +485,13 @@ class _MatmulEpilogue(torch.autograd.Function):
         return dx, db, dbias, dres, None
 
 
-def matmul_epilogue(x, b, bias=None, residual=None, slope=None):
+def matmul_epilogue(x, b, bias=None, residual=None, slope=None, out_f32=False):
     """act(x @ b + bias + residual): one MFMA kernel for tall operands (b is [K,N]); short operands
-    (deep layers, < GEMM_MIN_ROWS rows) go to rocBLAS through torch -- still on the GPU."""
+    (deep layers, < GEMM_MIN_ROWS rows) go to rocBLAS through torch -- still on the GPU.
+    bf16 rows (x.dtype bfloat16) always take the bf16 MFMA kernel; out_f32 keeps its output in f32."""
     _need_cuda(x, b)
+    if x.dtype == torch.bfloat16 and x.dim() == 2:
+        return _MatmulEpilogueBF16.apply(x, b, bias, residual, slope, bool(out_f32))
     if FUSED_EPILOGUE and x.dim() == 2 and x.shape[0] >= GEMM_MIN_ROWS and x.dtype == torch.float32:
         return _MatmulEpilogue.apply(x, b, bias, residual, slope)
     if not FUSED_EPILOGUE:
@@ -391,6 +512,8 @@ def matmul_epilogue(x, b, bias=None, residual=None, slope=None):
 def matmul(x, b):
     """x [M,K] @ b [K,N]: the MFMA kernels for tall operands, rocBLAS (torch.matmul on the GPU) for short ones"""
     _need_cuda(x, b)
+    if x.dtype == torch.bfloat16 and x.dim() == 2 and b.dim() == 2:
+        return _MatmulEpilogueBF16.apply(x, b, None, None, None, False)
     if x.dim() == 2 and b.dim() == 2 and x.shape[0] >= GEMM_MIN_ROWS and x.dtype == torch.float32:
         return _MatmulXB.apply(x, b)
     return torch.matmul(x, b)
@@ -404,6 +527,15 @@ def linear(x, weight):
 # ------------------------------------------------------------------------------------------------
 # pooling helpers (K7)
 # ------------------------------------------------------------------------------------------------
+def _by_dtype(lib, name, t):
+    """the f32 entry or its bf16-row form"""
+    if t.dtype == torch.bfloat16:
+        return getattr(lib, name + "_bf16")
+    if t.dtype != torch.float32:
+        raise _lib.WeasalHipError("%s: feature rows must be float32 or bfloat16 (got %s)" % (name, t.dtype))
+    return getattr(lib, name)
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, inds):
@@ -412,9 +544,9 @@ class _MaxPool(torch.autograd.Function):
         x = x.contiguous()
         ns, c = x.shape
         nq, h = inds.shape
-        out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
+        out = torch.empty((nq, c), dtype=x.dtype, device=x.device)
         arg = torch.empty((nq, c), dtype=torch.int32, device=x.device)
-        check(lib.ws_max_pool_fwd(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), ptr(arg), current_stream()))
+        check(_by_dtype(lib, "ws_max_pool_fwd", x)(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), ptr(arg), current_stream()))
         ctx.save_for_backward(arg, inds)
         ctx.ns = ns
         return out
@@ -426,9 +558,9 @@ class _MaxPool(torch.autograd.Function):
         nq, c = arg.shape
         h = inds.shape[1]
         table = transposed_table(inds, ctx.ns)
-        dx = torch.empty((ctx.ns, c), dtype=torch.float32, device=dy.device)
+        dx = torch.empty((ctx.ns, c), dtype=dy.dtype, device=dy.device)
         dy = dy.contiguous()
-        check(lib.ws_max_pool_bwd(ptr(dy), ptr(arg), nq, h, c, ptr(table.offsets), ptr(table.pairs), ctx.ns,
+        check(_by_dtype(lib, "ws_max_pool_bwd", dy)(ptr(dy), ptr(arg), nq, h, c, ptr(table.offsets), ptr(table.pairs), ctx.ns,
                                   ptr(dx), current_stream()))
         return dx, None
 
@@ -441,8 +573,8 @@ class _ClosestPool(torch.autograd.Function):
         x = x.contiguous()
         ns, c = x.shape
         nq, h = inds.shape
-        out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
-        check(lib.ws_closest_pool_fwd(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), current_stream()))
+        out = torch.empty((nq, c), dtype=x.dtype, device=x.device)
+        check(_by_dtype(lib, "ws_closest_pool_fwd", x)(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), current_stream()))
         # only the first column takes part (blocks.py:92): the backward needs the transposed
         # table of that column alone (lists of ~N_fine/N_coarse entries instead of ~H times that)
         ctx.key = (inds.data_ptr(), tuple(inds.shape), ns)
@@ -464,9 +596,9 @@ class _ClosestPool(torch.autograd.Function):
             if col0 is None:
                 raise _lib.WeasalHipError("closest_pool backward: the pre-built column-0 table was dropped before backward")
             table = TransposedTable(col0, ctx.ns)
-        dx = torch.empty((ctx.ns, c), dtype=torch.float32, device=dy.device)
+        dx = torch.empty((ctx.ns, c), dtype=dy.dtype, device=dy.device)
         dy = dy.contiguous()
-        check(lib.ws_closest_pool_bwd(ptr(dy), nq, 1, c, ptr(table.offsets), ptr(table.pairs), ctx.ns, ptr(dx),
+        check(_by_dtype(lib, "ws_closest_pool_bwd", dy)(ptr(dy), nq, 1, c, ptr(table.offsets), ptr(table.pairs), ctx.ns, ptr(dx),
                                       current_stream()))
         return dx, None
 
