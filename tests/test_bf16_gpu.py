@@ -13,7 +13,11 @@ Tolerances held (max|a-b| / max|ref| per tensor), and why:
   * one rigid KPConv layer, activations (wf and out rounded):           1e-2
   * its gradients dx / dW (dz, dwf, dx rounded; dW is an fp32 sum of products of rounded rows):   2e-2
   * deformable + modulated layer (the offsets come from a bf16-row convolution and move the kernel points,
-    so rounding enters the geometry):   out 2e-2, gradients 5e-2
+    so rounding enters the geometry):   out 2e-2; parameter gradients (sums over all points) 5e-2.  The gradient with
+    respect to the kernel-point positions is DISCONTINUOUS where a neighbour crosses the influence extent
+    (d w / d kp jumps from -(kp - n)/(extent |kp - n|) to 0, models/blocks.py:337), so a 1e-2 perturbation of the
+    offsets flips isolated neighbours and changes isolated entries of dx by O(10 %): dx is held in the relative
+    Frobenius norm (5e-2) with a loose max-norm guard (0.25)
   * pooling: bit-exact (max / copy of bf16 values).
 Integer outputs (neighbours, subsampling) are untouched by the feature dtype.
 """
@@ -31,6 +35,12 @@ def rel(a, ref):
     a = a.detach().double().cpu()
     ref = ref.detach().double().cpu()
     return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def rel2(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return ((a - ref).norm() / ref.norm().clamp_min(1e-30)).item()
 
 
 def rbf(t):
@@ -161,10 +171,13 @@ def test_deformable_kpconv_bf16_vs_oracle(gpu, modulated):
     assert rel(conv.min_d2, twin.min_d2) < 2e-2
     assert rel(out, ref) < 2e-2
     assert abs(float(reg) - float(reg_c)) < 2e-2 * abs(float(reg_c))
-    assert rel(xg.grad, xc.grad) < 5e-2
-    assert rel(conv.weights.grad, twin.weights.grad) < 5e-2
-    assert rel(conv.offset_conv.weights.grad, twin.offset_conv.weights.grad) < 5e-2
-    assert rel(conv.offset_bias.grad, twin.offset_bias.grad) < 5e-2
+    errs = {"dx_l2": rel2(xg.grad, xc.grad), "dx_max": rel(xg.grad, xc.grad),
+            "dW": rel(conv.weights.grad, twin.weights.grad),
+            "dW_off": rel(conv.offset_conv.weights.grad, twin.offset_conv.weights.grad),
+            "db_off": rel(conv.offset_bias.grad, twin.offset_bias.grad)}
+    print("bf16 deformable gradient errors:", errs)
+    assert errs["dx_l2"] < 5e-2 and errs["dx_max"] < 0.25, errs
+    assert errs["dW"] < 5e-2 and errs["dW_off"] < 5e-2 and errs["db_off"] < 5e-2, errs
 
 
 def test_pools_bf16_bit_exact(gpu):

@@ -397,7 +397,8 @@ class _MatmulEpilogueBF16(torch.autograd.Function):
             if dz.dtype == torch.bfloat16 and _bf16_ok(dz, n):
                 dx = _xbt16(lib, dz, b.to(torch.bfloat16).contiguous() if b.is_contiguous() else _bt16(b.t()), None, None, None, False)
             else:
-                dx = _gemm_xb(dz.float().contiguous(), b.t().float().contiguous()).to(torch.bfloat16)
+                # (the bf16-rounded weights the forward used, widened)
+                dx = _gemm_xb(dz.float().contiguous(), b.t().to(torch.bfloat16).float().contiguous()).to(torch.bfloat16)
         dz16 = dz if dz.dtype == torch.bfloat16 else dz.to(torch.bfloat16)
         if ctx.needs_input_grad[1]:
             db = _xty16(lib, x, dz16)
