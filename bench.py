@@ -35,9 +35,15 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def b_fwd(n, h, ci, co):
-    """algorithmic bytes of one fused KPConv forward"""
-    return n * h * (8 + 12 + 4 * ci) + n * (12 + 4 * co) + 60 * ci * co + 180
+def b_fwd(n, h, ci, co, es=4):
+    """algorithmic bytes of one fused KPConv forward (the "logical gather" model, every neighbour
+    reference counted once); es = bytes per feature element (4 = f32 rows, 2 = bf16 rows of config 5)"""
+    return n * h * (8 + 12 + es * ci) + n * (12 + es * co) + 4 * 15 * ci * co + 180
+
+
+def u_fwd(n, ns, h, ci, co, es=4):
+    """compulsory-unique bytes of the same layer: every index once, every support row once"""
+    return 8 * n * h + ns * (12 + es * ci) + n * (12 + es * co) + 4 * 15 * ci * co
 
 
 class KernelTimer:
@@ -70,16 +76,47 @@ class KernelTimer:
         return out
 
 
+def _pyramid_worker(args):
+    """one DataLoader-worker's share of the CPU pyramid (its own process, one thread)"""
+    import numpy as _np
+    from oracle import geom as _geom, pyramid_ref as _pr
+    from weasal_amd import config as _wcfg
+    from weasal_amd.synthetic import make_inputs as _mk
+    cfg_name, wl, seed = args
+    cfg = getattr(_wcfg, cfg_name)()
+    cfg.feature_dtype = 'f32'
+    pts, feats, labels, lens = _mk(seed, 1, wl["points"], wl["radius"], cfg.in_features_dim)
+    _np.random.seed(seed)
+    t0 = time.perf_counter()
+    _pr.segmentation_inputs(cfg, pts, feats, labels, lens, wl["limits"], kind="ref" if _geom.have_ref() else "port")
+    return time.perf_counter() - t0, int(lens.sum())
+
+
+def cpu_pyramid_rate(cfg_name, wl, procs):
+    """points/s of the CPU input pyramid with `procs` worker processes (the reference's input_threads = 10
+    DataLoader workers, train_DALES_PseudoLabel.py:291-296), one sphere each"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")              # fresh children: never fork a process that holds the GPU
+    with ctx.Pool(procs) as pool:
+        pool.map(_pyramid_worker, [(cfg_name, wl, 900 + i) for i in range(procs)])       # warm-up: imports, page-in
+        t0 = time.perf_counter()
+        res = pool.map(_pyramid_worker, [(cfg_name, wl, 100 + i) for i in range(procs)])
+        wall = time.perf_counter() - t0
+    return sum(n for _, n in res) / wall, wall
+
+
 def cpu_baseline(cfg_cls, wl, threads):
     """Reference CPU path on a bounded sample: ONE sphere of the workload through
     (a) the pyramid on the CPU geometry core, single thread like one DataLoader worker,
-    (b) KPFCNN forward + loss + backward in plain torch on all host threads."""
+    (b) KPFCNN forward + loss + backward in plain torch on all host threads;
+    plus (c) the pyramid rate of 10 worker processes (the reference's input_threads), one sphere each."""
     from oracle import geom, kpconv_ref, pyramid_ref
     from weasal_amd.architectures import KPFCNN
     from weasal_amd.pyramid import PyramidBatch
     from weasal_amd.synthetic import make_inputs
     torch.set_num_threads(threads)
     cfg = cfg_cls()
+    cfg.feature_dtype = 'f32'          # the CPU restatement is the reference's fp32 arithmetic
     kind = "ref" if geom.have_ref() else "port"
     pts, feats, labels, lens = make_inputs(12345, 1, wl["points"], wl["radius"], cfg.in_features_dim)
     np.random.seed(0)
@@ -96,7 +133,15 @@ def cpu_baseline(cfg_cls, wl, threads):
         loss.backward()
         t_model = time.perf_counter() - t0
     n = int(lens.sum())
+    procs = 10
+    try:
+        pyr10, wall10 = cpu_pyramid_rate(cfg_cls.__name__, wl, procs)
+    except Exception as e:          # reported, never fatal
+        pyr10, wall10 = None, repr(e)
     return {"value": n / (t_pyr + t_model), "unit": "points/s", "cores": threads,
+            "pyramid_points_per_s_1_thread": n / t_pyr,
+            "pyramid_points_per_s_10_processes": pyr10, "pyramid_10_processes_wall_s": wall10,
+            "model_points_per_s": n / t_model,
             "kind": "reference" if kind == "ref" else "port",
             "sample": "1 sphere x %d pts: pyramid %.2fs on 1 thread (%s geometry core) + KPFCNN fwd+bwd %.2fs "
                       "in plain torch (oracle/kpconv_ref.py restatement of models/blocks.py) on %d threads"
@@ -108,7 +153,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen", "dales_deform"])
+    ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen", "dales_deform", "dales_deform_f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--dp-buckets", type=int, default=int(os.environ.get("WEASAL_DP_BUCKETS", "1")),
@@ -161,6 +206,7 @@ def main():
 
     timer = KernelTimer()
     ops.set_kernel_timer(timer)
+    from weasal_amd import fused
 
     prefetcher = None
     if args.prefetch:
@@ -201,6 +247,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    fused.timer_reset()
+    fused.set_timed(True)            # HIP events around the K3 launches inside the block calls (launch stream)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -210,6 +258,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    fused.set_timed(False)
     if prefetcher is not None:
         prefetcher.close()
     if world > 1:
@@ -219,37 +268,58 @@ def main():
 
     if rank == 0:
         ms = 1000.0 * dt / args.steps
+        bf16 = getattr(cfg, 'feature_dtype', 'f32') == 'bf16'
+        es = 2 if bf16 else 4
+        backend = dist.get_backend() if world > 1 else None
+        exch = "" if world == 1 else (" + RCCL grad all-reduce" if backend == "nccl" else " + %s grad all-reduce (NOT RCCL: rehearsal backend)" % backend)
         res = {"metric": "points/sec fwd+bwd KPFCNN on DALES spheres; achieved HBM GB/s on KPConv gather",
                "value": world * n_points * args.steps / dt, "unit": "points/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "host_issue_ms_per_step": 1000.0 * t_enqueued / args.steps, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": wl["name"] + ", fp32, step = GPU pyramid + fwd + loss + bwd"
-                          + (" + RCCL grad all-reduce" if world > 1 else "") + " + SGD"
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+               "config": {"workload": wl["name"] + (", bf16 feature rows / fp32 accumulate / fp32 geometry" if bf16 else ", fp32")
+                          + ", step = GPU pyramid + fwd + loss + bwd" + exch + " + SGD"
+                          + ("; contrast_loss term included" if args.contrast else "; contrast_loss term (trainer_PseudoLabel.py:204-208) not in this step, see --contrast 1")
                           + ("; pyramid of the next batch overlapped on a second stream" if args.prefetch else ""),
                           "points_per_step_per_gpu": n_points, "parallelism": "dp%d" % world,
-                          "final_loss": float(loss.item())}}
-        # ---- roofline of the fused KPConv gather kernel on the largest layer
+                          "dist_backend": backend, "final_loss": float(loss.item())}}
+        # ---- roofline of the fused KPConv gather kernel (K3) on the largest layer: HIP events on the launch stream,
+        #      recorded inside the block calls (ws_timer_*) or around the operator launch (ops timer)
         summ = timer.summary()
-        fwd = {k: v for k, v in summ.items() if k[0] == "kpconv_gather_fwd"}
+        recs = {}
+        for nq_, h_, ci_, ms_ in fused.timer_records():
+            recs.setdefault(("kpconv_gather_fwd", nq_, h_, ci_), []).append(ms_)
+        for k_, v_ in recs.items():
+            if k_ in summ:
+                tot = summ[k_][0] * summ[k_][1] + sum(v_)
+                summ[k_] = (tot / (summ[k_][1] + len(v_)), summ[k_][1] + len(v_))
+            else:
+                summ[k_] = (float(np.mean(v_)), len(v_))
+        fwd = {k: v for k, v in summ.items() if k[0] == "kpconv_gather_fwd" and k[3] >= 8}
         if fwd:
-            ci_dom = 16 if args.workload == "vaihingen" else 32
-            cand = [k for k in fwd if k[3] == ci_dom]
-            key = max(cand or list(fwd), key=lambda k: k[1] * k[2] * k[3])
+            key = max(fwd, key=lambda k: b_fwd(k[1], k[2], k[3], k[3], es))     # the launch that moves the most bytes
             ms_k, count = fwd[key]
             _, nq, h, ci = key
-            bytes_alg = b_fwd(nq, h, ci, ci)
+            bytes_alg = b_fwd(nq, h, ci, ci, es)
             achieved = bytes_alg / (ms_k * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(REPO, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get("kpconv_gather_fwd_enc1_bytes_per_launch")
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("kpconv_gather_fwd_bytes_per_launch", {}).get("%s:%d:%d" % (args.workload, h, ci))
                 except Exception:
                     traffic = None
-            res["roofline"] = {"bound": "hbm", "kernel": "kpconv_gather_fwd_kernel<15,8,0,false,true> (enc1: N=%d, H=%d, Ci=%d)" % (nq, h, ci),
+            G = max(1, ci // 4)
+            res["roofline"] = {"bound": "hbm",
+                               "kernel": "kpconv_gather_fwd_kernel<15,%d,0,false,true,4,%s> (N=%d queries, H=%d, Ci=%d)"
+                                         % (min(G, 16), "bf16" if bf16 else "float", nq, h, ci),
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "achieved_is": "SURVEY 8d logical-gather bytes B_fwd / launch time (every neighbour reference "
+                                              "counted once; L2 reuse lets it exceed what HBM alone delivers)",
+                               "achieved_hbm_measured": (traffic / (ms_k * 1e-3) / 1e9) if traffic else None,
+                               "u_fwd_bytes": u_fwd(nq, nq, h, ci, ci, es),
                                "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": ms_k, "launches_timed": count}
             # per-launch means of the KPConv gather kernels, grouped by layer (N varies by a few points from
             # batch to batch with the random grid orientation: rounded to two significant digits)

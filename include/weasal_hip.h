@@ -360,6 +360,99 @@ int64_t ws_act_bwd_colsum_bf16_scratch_bytes(int64_t m, int32_t n);
 int ws_act_bwd_colsum_bf16(const void* dy, int32_t dy_f32, int64_t m, int32_t n, int64_t lddy, const uint16_t* y, int64_t ldy,
                            float slope, uint16_t* dz, int64_t lddz, float* colsum, void* scratch, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Whole network blocks behind ONE call each (rigid KPConv, linear influence, sum aggregation, f32 rows).
+ *
+ * The reference runs a block as ~10 separate torch ops plus their autograd nodes (models/blocks.py:510-564
+ * SimpleBlock, :624-709 ResnetBottleneckBlock; the decoder step models/architectures.py:339-343: nearest_upsample ->
+ * concat(skip) -> unary); driven from Python each launch costs ~15 us of host time, more than most of these kernels
+ * take.  ws_kpblock_fwd / _bwd launch the whole sequence from C on one stream:
+ *
+ *   x1   = lrelu(feat @ w1^T + b1)                          unary1   (absent when w1 == NULL: x1 = feat)
+ *   wf   = gather(x1)                                       K3, ws_kpconv_gather_fwd
+ *   x2   = lrelu(wf @ wk + bk)                              the kernel contraction + BatchNormBlock bias + LeakyReLU
+ *   out  = lrelu(x2 @ w2^T + b2 + shortcut)                 unary2 + residual sum (absent when w2 == NULL: out = x2)
+ *   shortcut = max_pool(feat, inds) if strided else feat,   then @ ws^T + bs when ws != NULL
+ *
+ * and in the backward every gradient accumulation is the residual operand of a GEMM epilogue (no separate adds),
+ * LeakyReLU' and the bias gradients share one pass (ws_act_bwd_colsum), dX of the KPConv goes through the search grid
+ * of the level (ws_kpconv_gather_bwd_x_grid) when grid_blob != NULL, else through the transposed table.
+ * Linear weights are nn.Linear's [out,in] row-major; wk is KPConv.weights [k, conv_in, conv_out] (blocks.py:171).
+ * Biases may be NULL (BatchNormBlock with use_bn is an identity, blocks.py:453-463).
+ * Requirements (WS_ERR_UNSUPPORTED otherwise; the caller then runs the operators one by one): in_dim, conv_out,
+ * out_dim multiples of 4 and conv_in a multiple of 4 (or the 3..4-channel input layer without unary1), k = 15.
+ * All buffers are caller-owned; `scratch` must hold ws_kpblock_*_scratch_bytes(desc) bytes.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ws_kpblock {
+    /* geometry of the convolution */
+    const float* q_pts; int64_t nq;
+    const float* s_pts; int64_t ns;
+    const int64_t* inds; int32_t h;
+    const float* kernel_points; int32_t k; float extent;
+    const int32_t* order_q;              /* scheduling hints (NULL allowed) */
+    const int32_t* order_s;
+    /* dX route: search grid of a self-query level ... */
+    const void* grid_blob; int32_t grid_nb; int64_t grid_cells; const uint64_t* key_last; float grid_radius;
+    int32_t* grid_overflow;
+    /* ... or the transposed table of inds (also used by the max-pool shortcut of strided blocks) */
+    const int32_t* t_offsets; const int32_t* t_pairs;
+    /* widths */
+    int32_t in_dim, conv_in, conv_out, out_dim, strided;
+    float slope;
+    /* parameters */
+    const float *w1, *b1, *wk, *bk, *w2, *b2, *ws, *bs;
+    /* activations: feat [ns,in_dim] in; x1 [ns,conv_in] (w1 != NULL), wf [nq,k*conv_in], x2 [nq,conv_out] (w2 != NULL),
+     * pooled [nq,in_dim] + arg (strided with w2), out [nq,out_dim]: written by fwd, read by bwd */
+    const float* feat; float* x1; float* wf; float* x2; float* pooled; int32_t* arg; float* out;
+    /* backward: dout [nq,out_dim] in; gradients out (dfeat NULL = not wanted; parameter gradients NULL where the
+     * parameter is NULL; the shortcut bias gradient equals db2) */
+    const float* dout; float* dfeat; float *dw1, *db1, *dwk, *dbk, *dw2, *db2, *dws;
+    int32_t timed;                       /* 1: bracket the K3 launch with HIP events (ws_timer_*) */
+} ws_kpblock;
+
+int64_t ws_kpblock_fwd_scratch_bytes(const ws_kpblock* d);
+int64_t ws_kpblock_bwd_scratch_bytes(const ws_kpblock* d);
+int ws_kpblock_fwd(const ws_kpblock* d, void* scratch, int64_t scratch_bytes, void* stream);
+int ws_kpblock_bwd(const ws_kpblock* d, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* Decoder step (models/architectures.py:339-343 + blocks.py:473-507): with the unary's weight w = [wx | wsk]
+ * ([out, c_up + c_skip], leading dimension ldw), evaluated as
+ *   yc  = xc @ wx^T                        at the coarse resolution [nc,out]
+ *   out = lrelu(skip @ wsk^T + b + yc[ups[:,0]])          (closest_pool = nearest upsampling, blocks.py:80-92)
+ * identical in exact arithmetic to upsample -> concat -> unary (a row gather commutes with a per-row linear map).
+ * Backward: dw [out, c_up + c_skip] (same layout as w), db, dxc [nc,c_up], dskip [nf,c_skip]; t_offsets / t_pairs =
+ * transposed table of column 0 of `ups`. */
+typedef struct ws_upunary {
+    const float* xc; int64_t nc; int32_t c_up;
+    const float* skip; int64_t nf; int32_t c_skip;
+    const int64_t* ups; int32_t h_up;
+    const int32_t* t_offsets; const int32_t* t_pairs;
+    const float* w; int64_t ldw; const float* b; int32_t out_dim; int32_t relu; float slope;
+    float* yc; float* out;               /* fwd outputs (yc is scratch-like but caller-owned: not needed by bwd) */
+    const float* dout; float* dxc; float* dskip; float* dw; float* db;
+} ws_upunary;
+
+int64_t ws_upunary_fwd_scratch_bytes(const ws_upunary* d);
+int64_t ws_upunary_bwd_scratch_bytes(const ws_upunary* d);
+int ws_upunary_fwd(const ws_upunary* d, void* scratch, int64_t scratch_bytes, void* stream);
+int ws_upunary_bwd(const ws_upunary* d, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* y = act(x @ B + bias + residual) with a strided small matrix: B[kk][col] = b[kk*b_row_stride + col*b_col_stride]
+ * (b_row_stride = 1, b_col_stride = K reads nn.Linear's [N,K] weight as its transpose in place).  Strided forms need
+ * k % 32 == 0, n % 4 == 0 and 16-byte aligned rows. */
+int ws_gemm_xb_epilogue_strided(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride,
+                                int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
+                                int32_t act, float slope, float* y, int64_t ldy, void* scratch, int64_t scratch_bytes,
+                                void* stream);
+
+/* HIP-event timing of selected kernel launches inside the block calls (bench.py's roofline figure): events are
+ * recorded on the launch stream around the K3 launch of blocks with timed = 1.  ws_timer_read synchronises on the
+ * events of record i and returns its key (nq, h, ci) and the elapsed milliseconds. */
+int ws_timer_reset(void);
+int ws_timer_count(void);
+int ws_timer_read(int32_t i, int64_t* nq, int32_t* h, int32_t* ci, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

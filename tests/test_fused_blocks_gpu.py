@@ -1,0 +1,100 @@
+"""GPU: whole blocks behind one C call each way (ws_kpblock_fwd/_bwd, ws_upunary_fwd/_bwd; weasal_amd/fused.py) against
+the operator-by-operator path of weasal_amd/blocks.py (the form round 1 pinned against goldens g4/g8) on the same
+inputs.  Same kernels and the same order inside every sum; the only re-association is where a gradient accumulation
+became the residual operand of a GEMM epilogue (a + b in one order instead of the other), so outputs must agree
+bit for bit and gradients to 1e-6 of max|ref|.  The golden network test (tests/test_pyramid_gpu.py::
+test_kpfcnn_step_vs_golden) and the full-width oracle tests run through the block calls as well."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _run(gpu, cfg, fused_on, seed=3, steps=1):
+    from weasal_amd import fused, pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    from weasal_amd.trainer import make_optimizer, train_step
+    fused.FUSED_BLOCKS = fused_on
+    try:
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        net = KPFCNN(cfg, np.arange(9), []).to(gpu).train()
+        opt = make_optimizer(net, cfg)
+        pts, feats, labels, lens = synthetic.make_inputs(21, 3, 4000, 4.0, cfg.in_features_dim)
+        np.random.seed(8)
+        batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu),
+                                    torch.from_numpy(labels).to(gpu), lens, [40, 45, 50, 50, 40])
+        for _ in range(steps):
+            loss, out = train_step(net, opt, batch, cfg)
+        torch.cuda.synchronize()
+        grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        params = {k: p.detach().clone() for k, p in net.named_parameters()}
+        return out.detach().clone(), loss.item(), grads, params
+    finally:
+        fused.FUSED_BLOCKS = True
+
+
+@pytest.mark.parametrize("cfg_name", ["DALESPLConfig", "Vaihingen3DPLConfig"])
+def test_block_calls_match_operator_path(gpu, cfg_name):
+    from weasal_amd import config as wcfg
+    cfg = getattr(wcfg, cfg_name)()
+    cfg.dropout = 0.0
+    out_f, loss_f, g_f, p_f = _run(gpu, cfg, True)
+    out_o, loss_o, g_o, p_o = _run(gpu, cfg, False)
+    assert torch.equal(out_f, out_o)                      # forward: the same kernels in the same order
+    assert loss_f == loss_o
+    assert set(g_f) == set(g_o) and len(g_f) > 60
+    for k in g_o:
+        assert rel(g_f[k], g_o[k]) < 1e-6, k
+    for k in p_o:
+        assert rel(p_f[k], p_o[k]) < 1e-6, k
+
+
+def test_block_calls_are_taken_and_launch_fewer_kernels(gpu):
+    """the rigid f32 network really runs through the block calls (one autograd node per block)"""
+    from weasal_amd import config as wcfg, fused
+    cfg = wcfg.DALESPLConfig()
+    cfg.dropout = 0.0
+    calls = {"kp": 0, "up": 0}
+    kp_apply, up_apply = fused._KPBlockFn.apply, fused._UpUnaryFn.apply
+
+    def kp(*a):
+        calls["kp"] += 1
+        return kp_apply(*a)
+
+    def up(*a):
+        calls["up"] += 1
+        return up_apply(*a)
+    fused._KPBlockFn.apply, fused._UpUnaryFn.apply = kp, up
+    try:
+        _run(gpu, cfg, True)
+    finally:
+        fused._KPBlockFn.apply, fused._UpUnaryFn.apply = kp_apply, up_apply
+    assert calls == {"kp": 10, "up": 4}, calls
+
+
+def test_kpblock_rejects_unsupported_shapes_loudly(gpu):
+    """descriptor validation: K != 15 and widths that are not multiples of 4 are WS_ERR_UNSUPPORTED, not silence"""
+    import ctypes as C
+    from weasal_amd import _lib, fused
+    lib = _lib.lib()
+    d = fused.KPBlockDesc()
+    x = torch.zeros(64, device=gpu)
+    for f in ("q_pts", "s_pts", "inds", "kernel_points", "feat", "wk", "wf", "out"):
+        setattr(d, f, x.data_ptr())
+    d.nq = d.ns = 4
+    d.h, d.k, d.extent = 3, 7, 1.0
+    d.in_dim = d.conv_in = 8
+    d.conv_out = d.out_dim = 8
+    assert lib.ws_kpblock_fwd_scratch_bytes(C.byref(d)) == -1 and b"K=15" in lib.ws_last_error()
+    d.k = 15
+    d.conv_out = d.out_dim = 6
+    assert lib.ws_kpblock_fwd_scratch_bytes(C.byref(d)) == -1 and b"multiples of 4" in lib.ws_last_error()
+    d.conv_out = d.out_dim = 8
+    assert lib.ws_kpblock_fwd_scratch_bytes(C.byref(d)) > 0

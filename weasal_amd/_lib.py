@@ -87,6 +87,20 @@ SIGNATURES = {
     "ws_gemm_xty_bf16": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp]),
     "ws_act_bwd_colsum_bf16_scratch_bytes": (_i64, [_i64, _i32]),
     "ws_act_bwd_colsum_bf16": (C.c_int, [_vp, _i32, _i64, _i32, _i64, _vp, _i64, C.c_float, _vp, _i64, _vp, _vp, _vp]),
+    # whole blocks behind one call (descriptor structs: weasal_amd/fused.py mirrors them as ctypes.Structure)
+    "ws_kpblock_fwd_scratch_bytes": (_i64, [_vp]),
+    "ws_kpblock_bwd_scratch_bytes": (_i64, [_vp]),
+    "ws_kpblock_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ws_kpblock_bwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ws_upunary_fwd_scratch_bytes": (_i64, [_vp]),
+    "ws_upunary_bwd_scratch_bytes": (_i64, [_vp]),
+    "ws_upunary_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ws_upunary_bwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ws_gemm_xb_epilogue_strided": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _i64,
+                                              _vp, _i64, _vp]),
+    "ws_timer_reset": (C.c_int, []),
+    "ws_timer_count": (C.c_int, []),
+    "ws_timer_read": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import fused, ops
 from .blocks import KPConv, NearestUpsampleBlock, UnaryBlock, block_decider, closest_pool
 
 _LAYER_CHANGE = ('pool', 'strided', 'upsample', 'global')
@@ -125,6 +125,8 @@ class KPFCNN(nn.Module):
             self.head_softmax.out_f32 = True
 
     def _fused_upsample_unary(self, x, skip, up_block, unary, batch):
+        if fused.upunary_eligible(x, skip, unary):
+            return fused.upunary(x, skip, unary, batch.upsamples[up_block.layer_ind - 1])   # one C call each way
         c_up = x.shape[1]
         w = unary.mlp.weight
         y = closest_pool(ops.linear(x, w[:, :c_up]), batch.upsamples[up_block.layer_ind - 1])

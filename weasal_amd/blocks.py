@@ -23,7 +23,7 @@ import torch.nn as nn
 from torch.nn.init import kaiming_uniform_
 from torch.nn.parameter import Parameter
 
-from . import ops
+from . import fused, ops
 from .kernel_points import load_kernels
 
 
@@ -282,6 +282,8 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
+        if fused.kpblock_eligible(self, x):
+            return fused.simple_block(self, x, batch, q_pts, s_pts, inds)      # one C call each way (csrc/blocks.hip)
         return self.KPConv(q_pts, s_pts, inds, x, _bias=self.batch_norm.epilogue_bias(), _slope=0.1)
 
 
@@ -302,6 +304,8 @@ class SimpleBlock2(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
+        if fused.kpblock_eligible(self, x):
+            return fused.simple_block(self, x, batch, q_pts, s_pts, inds)      # one C call each way (csrc/blocks.hip)
         return self.KPConv(q_pts, s_pts, inds, x, _bias=self.batch_norm.epilogue_bias(), _slope=0.1)
 
 
@@ -330,6 +334,8 @@ class ResnetBottleneckBlock(nn.Module):
 
     def forward(self, features, batch):
         q_pts, s_pts, inds = _layer_geometry(self.block_name, self.layer_ind, batch)
+        if fused.kpblock_eligible(self, features):
+            return fused.resnetb_block(self, features, batch, q_pts, s_pts, inds)   # one C call each way (csrc/blocks.hip)
         x = self.unary1(features)
         x = self.KPConv(q_pts, s_pts, inds, x, _bias=self.batch_norm_conv.epilogue_bias(), _slope=0.1)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features

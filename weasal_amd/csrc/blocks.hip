@@ -1,0 +1,426 @@
+// weasal_amd/csrc/blocks.hip -- whole network blocks behind one C call (host code: launch sequences over the kernels
+// of kpconv.hip / gemm.hip / pools.hip on one stream).
+//
+// Reference units: models/blocks.py:510-564 (SimpleBlock), :624-709 (ResnetBottleneckBlock) and their autograd;
+// models/architectures.py:339-343 + blocks.py:473-507 (nearest_upsample -> concat -> unary).  The reference runs each
+// of them as ~10 torch ops plus autograd nodes driven from Python; here one call launches the 6-7 (forward) or 10-14
+// (backward) kernels back to back, every gradient accumulation is the residual operand of a GEMM epilogue and the
+// scratch comes from one caller-owned arena (no allocation, no host synchronisation).
+#include <vector>
+
+#include "ws_common.h"
+
+namespace {
+
+struct Arena {
+    char* base;
+    int64_t cap, off;
+    Arena(void* b, int64_t c) : base((char*)b), cap(c), off(0) {}
+    template <typename T> T* take(int64_t count)
+    {
+        off = (off + 255) & ~(int64_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * (int64_t)sizeof(T);
+        return p;
+    }
+    bool fits() const { return off <= cap; }
+};
+
+inline int64_t max3(int64_t a, int64_t b, int64_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+__global__ __launch_bounds__(256) void transpose_small_kernel(const float* __restrict__ w, int rows, int cols, int64_t ld,
+                                                               float* __restrict__ out)
+{
+    // out[c][r] = w[r*ld + c]   (weights: a few hundred KB at most)
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)rows * cols) return;
+    const int c = (int)(e / rows), r = (int)(e % rows);
+    out[e] = w[(int64_t)r * ld + c];
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n4)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        float4 x = reinterpret_cast<float4*>(a)[e];
+        const float4 y = reinterpret_cast<const float4*>(b)[e];
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        reinterpret_cast<float4*>(a)[e] = x;
+    }
+}
+
+// y = act(x [m,k] @ w^T + bias + residual), w = nn.Linear weight [n,k] with leading dimension ldw, read in place as
+// its transpose when the strided MFMA path takes the shape, through an explicit transpose in `tr` otherwise
+struct Lin {
+    const float* w; int n, k; int64_t ldw;
+    bool in_place() const { return k % 32 == 0 && n % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)w & 15u) == 0; }
+    int64_t tr_floats() const { return in_place() ? 0 : (int64_t)k * n; }
+};
+
+int linear_fwd(const Lin& l, const float* x, int64_t m, int64_t ldx, const float* bias, const float* residual, int64_t ldr,
+               int act, float slope, float* y, float* tr, void* tmp, int64_t tmp_bytes, hipStream_t st)
+{
+    if (l.in_place())
+        return ws_gemm_xb_epilogue_strided(x, m, l.k, ldx, l.w, 1, l.ldw, l.n, bias, residual, ldr, act, slope, y, l.n, tmp, tmp_bytes, st);
+    transpose_small_kernel<<<(unsigned)ws_ceil_div((int64_t)l.k * l.n, 256), 256, 0, st>>>(l.w, l.n, l.k, l.ldw, tr);
+    return ws_gemm_xb_epilogue_strided(x, m, l.k, ldx, tr, l.n, 1, l.n, bias, residual, ldr, act, slope, y, l.n, tmp, tmp_bytes, st);
+}
+
+#define WS_TRY(call)            \
+    do {                        \
+        int rc__ = (call);      \
+        if (rc__) return rc__;  \
+    } while (0)
+
+// ---- launch timer (bench.py: HIP events around the K3 launch, on the launch stream) --------------------------
+struct TimerRec { hipEvent_t a, b; int64_t nq; int32_t h, ci; };
+std::vector<TimerRec>& timer_recs() { static std::vector<TimerRec> v; return v; }
+
+int check_kpblock(const ws_kpblock* d)
+{
+    WS_REQUIRE(d, "NULL descriptor");
+    WS_REQUIRE(d->nq >= 0 && d->ns >= 0 && d->h >= 1, "bad sizes nq=%lld ns=%lld h=%d", (long long)d->nq, (long long)d->ns, d->h);
+    if (d->k != 15) return ws_fail(WS_ERR_UNSUPPORTED, "num_kernel_points=%d: K=15 only", d->k);
+    WS_REQUIRE(d->in_dim >= 1 && d->conv_in >= 1 && d->conv_out >= 1 && d->out_dim >= 1, "bad widths");
+    WS_REQUIRE(d->q_pts && d->s_pts && d->inds && d->kernel_points && d->feat && d->wk && d->wf && d->out, "NULL argument");
+    WS_REQUIRE(d->w1 ? (d->x1 != nullptr) : (d->conv_in == d->in_dim), "unary1: x1 buffer missing or conv_in != in_dim");
+    WS_REQUIRE(d->w2 ? (d->x2 != nullptr) : (d->out_dim == d->conv_out), "unary2: x2 buffer missing or out_dim != conv_out");
+    WS_REQUIRE(!d->w2 || d->ws || d->in_dim == d->out_dim, "shortcut needs a projection (ws) when in_dim != out_dim");
+    WS_REQUIRE(!d->strided || !d->w2 || (d->pooled && d->arg), "strided block: pooled / arg buffers missing");
+    WS_REQUIRE(d->strided || d->nq == d->ns, "non-strided block: nq must equal ns");
+    if (d->conv_out % 4 || d->out_dim % 4 || (d->w1 && d->conv_in % 4) || (d->w2 && d->in_dim % 4))
+        return ws_fail(WS_ERR_UNSUPPORTED, "block widths must be multiples of 4 (in=%d conv=%d->%d out=%d)", d->in_dim, d->conv_in,
+                       d->conv_out, d->out_dim);
+    return WS_OK;
+}
+
+int64_t kpblock_tmp_fwd(const ws_kpblock* d)
+{
+    int64_t t = ws_gemm_xb_scratch_bytes(d->nq, d->k * d->conv_in, d->conv_out);
+    if (d->w1) t = max3(t, ws_gemm_xb_scratch_bytes(d->ns, d->in_dim, d->conv_in), 0);
+    if (d->w2) t = max3(t, ws_gemm_xb_scratch_bytes(d->nq, d->conv_out, d->out_dim), d->ws ? ws_gemm_xb_scratch_bytes(d->nq, d->in_dim, d->out_dim) : 0);
+    return t;
+}
+
+int kpblock_fwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
+{
+    const int64_t nq = d->nq, ns = d->ns;
+    const Lin l1{d->w1, d->conv_in, d->in_dim, d->in_dim}, l2{d->w2, d->out_dim, d->conv_out, d->conv_out},
+        lsc{d->ws, d->out_dim, d->in_dim, d->in_dim};
+    float* tr1 = d->w1 ? ar.take<float>(l1.tr_floats()) : nullptr;
+    float* tr2 = d->w2 ? ar.take<float>(l2.tr_floats()) : nullptr;
+    float* trs = d->ws ? ar.take<float>(lsc.tr_floats()) : nullptr;
+    float* sc = (d->w2 && d->ws) ? ar.take<float>(nq * d->out_dim) : nullptr;
+    const int64_t tmp_bytes = kpblock_tmp_fwd(d);
+    void* tmp = ar.take<char>(tmp_bytes > 16 ? tmp_bytes : 16);
+    if (!run) return WS_OK;
+    if (nq == 0) return WS_OK;
+    const float* x1 = d->feat;
+    if (d->w1) {
+        WS_TRY(linear_fwd(l1, d->feat, ns, d->in_dim, d->b1, nullptr, 0, 1, d->slope, d->x1, tr1, tmp, tmp_bytes, st));
+        x1 = d->x1;
+    }
+    TimerRec rec{};
+    if (d->timed) {
+        WS_HIP(hipEventCreate(&rec.a));
+        WS_HIP(hipEventCreate(&rec.b));
+        rec.nq = nq; rec.h = d->h; rec.ci = d->conv_in;
+        WS_HIP(hipEventRecord(rec.a, st));
+    }
+    WS_TRY(ws_kpconv_gather_fwd(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, x1, d->conv_in, d->kernel_points, d->k, nullptr, nullptr,
+                                d->extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, d->order_q, d->wf, nullptr, st));
+    if (d->timed) {
+        WS_HIP(hipEventRecord(rec.b, st));
+        timer_recs().push_back(rec);
+    }
+    float* x2 = d->w2 ? d->x2 : d->out;
+    WS_TRY(ws_gemm_xb_epilogue_strided(d->wf, nq, d->k * d->conv_in, (int64_t)d->k * d->conv_in, d->wk, d->conv_out, 1, d->conv_out,
+                                       d->bk, nullptr, 0, 1, d->slope, x2, d->conv_out, tmp, tmp_bytes, st));
+    if (!d->w2) return WS_OK;
+    const float* sc_in = d->feat;
+    if (d->strided) {
+        WS_TRY(ws_max_pool_fwd(d->feat, ns, d->in_dim, d->inds, nq, d->h, d->pooled, d->arg, st));
+        sc_in = d->pooled;
+    }
+    const float* res = sc_in;
+    int64_t ldr = d->in_dim;
+    if (d->ws) {
+        WS_TRY(linear_fwd(lsc, sc_in, nq, d->in_dim, d->bs, nullptr, 0, 0, 0.0f, sc, trs, tmp, tmp_bytes, st));
+        res = sc;
+        ldr = d->out_dim;
+    }
+    return linear_fwd(l2, x2, nq, d->conv_out, d->b2, res, ldr, 1, d->slope, d->out, tr2, tmp, tmp_bytes, st);
+}
+
+int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
+{
+    const int64_t nq = d->nq, ns = d->ns;
+    const int kc = d->k * d->conv_in;
+    const bool need_dx1 = d->dfeat != nullptr || d->w1 != nullptr;
+    const bool want_sc = d->w2 && d->dfeat;                       // the shortcut's share of dfeat
+    // ---- arena plan (identical in the size query and in the run)
+    float* dz = d->w2 ? ar.take<float>(nq * d->out_dim) : nullptr;
+    float* g2 = ar.take<float>(nq * d->conv_out);                  // dx2 -> dz2 (simple block: dz2 of dout)
+    float* dwf = need_dx1 ? ar.take<float>(nq * (int64_t)kc) : nullptr;
+    float* dx1 = (need_dx1 && d->w1) ? ar.take<float>(ns * d->conv_in) : nullptr;
+    float* dscin = (want_sc && d->ws) ? ar.take<float>(nq * d->in_dim) : nullptr;
+    float* dfsc = (want_sc && d->strided) ? ar.take<float>(ns * d->in_dim) : nullptr;
+    const Lin lk{d->wk, kc, d->conv_out, d->conv_out};           // dwf = dz2 @ wk^T: wk [kc, conv_out] read as a "Linear" weight
+    float* trk = need_dx1 ? ar.take<float>(lk.tr_floats()) : nullptr;
+    int64_t tmp_bytes = max3(ws_act_bwd_colsum_scratch_bytes(nq, d->out_dim > d->conv_out ? d->out_dim : d->conv_out),
+                             ws_act_bwd_colsum_scratch_bytes(ns, d->conv_in), ws_gemm_xty_scratch_bytes(nq, kc, d->conv_out));
+    if (d->w2) tmp_bytes = max3(tmp_bytes, ws_gemm_xty_scratch_bytes(nq, d->out_dim, d->conv_out),
+                                d->ws ? ws_gemm_xty_scratch_bytes(nq, d->out_dim, d->in_dim) : 0);
+    if (d->w1) tmp_bytes = max3(tmp_bytes, ws_gemm_xty_scratch_bytes(ns, d->conv_in, d->in_dim), 0);
+    tmp_bytes = max3(tmp_bytes, ws_gemm_xb_scratch_bytes(nq, d->conv_out, kc), ws_gemm_xb_scratch_bytes(nq, d->out_dim, d->conv_out));
+    tmp_bytes = max3(tmp_bytes, ws_gemm_xb_scratch_bytes(nq, d->out_dim, d->in_dim), ws_gemm_xb_scratch_bytes(ns, d->conv_in, d->in_dim));
+    void* tmp = ar.take<char>(tmp_bytes > 16 ? tmp_bytes : 16);
+    if (!run) return WS_OK;
+    WS_REQUIRE(d->dout && d->dwk, "NULL gradient buffer");
+    WS_REQUIRE(!d->w1 || d->dw1, "dw1 missing");
+    WS_REQUIRE(!d->w2 || d->dw2, "dw2 missing");
+    WS_REQUIRE(!d->ws || !d->w2 || d->dws, "dws missing");
+    if (nq == 0 || ns == 0) {
+        // no rows: every gradient is zero
+        WS_HIP(hipMemsetAsync(d->dwk, 0, sizeof(float) * (size_t)kc * d->conv_out, st));
+        if (d->dbk) WS_HIP(hipMemsetAsync(d->dbk, 0, sizeof(float) * d->conv_out, st));
+        if (d->w1) { WS_HIP(hipMemsetAsync(d->dw1, 0, sizeof(float) * (size_t)d->conv_in * d->in_dim, st)); if (d->db1) WS_HIP(hipMemsetAsync(d->db1, 0, sizeof(float) * d->conv_in, st)); }
+        if (d->w2) { WS_HIP(hipMemsetAsync(d->dw2, 0, sizeof(float) * (size_t)d->out_dim * d->conv_out, st)); if (d->db2) WS_HIP(hipMemsetAsync(d->db2, 0, sizeof(float) * d->out_dim, st)); }
+        if (d->w2 && d->ws) WS_HIP(hipMemsetAsync(d->dws, 0, sizeof(float) * (size_t)d->out_dim * d->in_dim, st));
+        if (d->dfeat && ns > 0) WS_HIP(hipMemsetAsync(d->dfeat, 0, sizeof(float) * (size_t)ns * d->in_dim, st));
+        return WS_OK;
+    }
+    const float* sc_res = nullptr;          // the shortcut's gradient w.r.t. feat rows [ns,in_dim]
+    const float* gin = d->dout;             // gradient entering the convolution's activation
+    const float* yconv = d->out;
+    if (d->w2) {
+        // dz = dout * lrelu'(out), db2 = column sums
+        WS_TRY(ws_act_bwd_colsum(d->dout, nq, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, dz, d->out_dim, d->db2, tmp, st));
+        WS_TRY(ws_gemm_xty(dz, nq, d->out_dim, d->out_dim, d->x2, d->conv_out, d->conv_out, d->dw2, tmp, st));
+        if (d->ws) {
+            const float* sc_in = d->strided ? d->pooled : d->feat;
+            WS_TRY(ws_gemm_xty(dz, nq, d->out_dim, d->out_dim, sc_in, d->in_dim, d->in_dim, d->dws, tmp, st));
+        }
+        if (want_sc) {
+            const float* dsc = dz;          // [nq, in_dim] when there is no projection (in_dim == out_dim)
+            if (d->ws) {
+                WS_TRY(ws_gemm_xb_epilogue_strided(dz, nq, d->out_dim, d->out_dim, d->ws, d->in_dim, 1, d->in_dim, nullptr, nullptr, 0, 0,
+                                                   0.0f, dscin, d->in_dim, tmp, tmp_bytes, st));
+                dsc = dscin;
+            }
+            if (d->strided) {
+                WS_REQUIRE(d->t_offsets && d->t_pairs, "strided block backward needs the transposed table");
+                WS_TRY(ws_max_pool_bwd(dsc, d->arg, nq, d->h, d->in_dim, d->t_offsets, d->t_pairs, ns, dfsc, st));
+                sc_res = dfsc;
+            } else {
+                sc_res = dsc;
+            }
+        }
+        // dx2 = dz @ w2
+        WS_TRY(ws_gemm_xb_epilogue_strided(dz, nq, d->out_dim, d->out_dim, d->w2, d->conv_out, 1, d->conv_out, nullptr, nullptr, 0, 0, 0.0f,
+                                           g2, d->conv_out, tmp, tmp_bytes, st));
+        gin = g2;
+        yconv = d->x2;
+    }
+    // dz2 = g * lrelu'(x2), dbk
+    WS_TRY(ws_act_bwd_colsum(gin, nq, d->conv_out, d->conv_out, yconv, d->conv_out, d->slope, g2, d->conv_out, d->dbk, tmp, st));
+    WS_TRY(ws_gemm_xty(d->wf, nq, kc, kc, g2, d->conv_out, d->conv_out, d->dwk, tmp, st));
+    if (!need_dx1) return WS_OK;
+    // dwf = dz2 @ wk^T
+    WS_TRY(linear_fwd(lk, g2, nq, d->conv_out, nullptr, nullptr, 0, 0, 0.0f, dwf, trk, tmp, tmp_bytes, st));
+    float* dx1_out = d->w1 ? dx1 : d->dfeat;
+    if (d->grid_blob) {
+        WS_REQUIRE(d->key_last && d->grid_overflow && nq == ns, "grid backward needs key_last / overflow and a self-query layer");
+        WS_TRY(ws_kpconv_gather_bwd_x_grid(d->s_pts, ns, d->grid_blob, d->grid_nb, d->grid_cells, d->key_last, d->grid_radius, dwf,
+                                           d->conv_in, d->kernel_points, d->k, nullptr, nullptr, d->extent, WS_INFLUENCE_LINEAR,
+                                           WS_AGGREGATION_SUM, d->order_s, dx1_out, d->grid_overflow, st));
+    } else {
+        WS_REQUIRE(d->t_offsets && d->t_pairs, "KPConv backward needs the search grid or the transposed table");
+        WS_TRY(ws_kpconv_gather_bwd_x(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, d->t_offsets, d->t_pairs, dwf, d->conv_in,
+                                      d->kernel_points, d->k, nullptr, nullptr, d->extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM,
+                                      d->order_s, dx1_out, st));
+    }
+    if (d->w1) {
+        WS_TRY(ws_act_bwd_colsum(dx1, ns, d->conv_in, d->conv_in, d->x1, d->conv_in, d->slope, dx1, d->conv_in, d->db1, tmp, st));
+        WS_TRY(ws_gemm_xty(dx1, ns, d->conv_in, d->conv_in, d->feat, d->in_dim, d->in_dim, d->dw1, tmp, st));
+        if (d->dfeat)
+            WS_TRY(ws_gemm_xb_epilogue_strided(dx1, ns, d->conv_in, d->conv_in, d->w1, d->in_dim, 1, d->in_dim, nullptr, sc_res, d->in_dim,
+                                               0, 0.0f, d->dfeat, d->in_dim, tmp, tmp_bytes, st));
+    } else if (d->dfeat && sc_res) {
+        const int64_t n4 = ns * d->in_dim / 4;
+        add_rows_kernel<<<ws_grid(n4, 256), 256, 0, st>>>(d->dfeat, sc_res, n4);
+        WS_LAUNCH_CHECK();
+    }
+    return WS_OK;
+}
+
+// ---- decoder step ------------------------------------------------------------------------------------------------
+int check_upunary(const ws_upunary* d)
+{
+    WS_REQUIRE(d, "NULL descriptor");
+    WS_REQUIRE(d->nc >= 0 && d->nf >= 0 && d->c_up >= 1 && d->c_skip >= 1 && d->out_dim >= 1 && d->h_up >= 1, "bad sizes");
+    WS_REQUIRE(d->xc && d->skip && d->ups && d->w && d->yc && d->out && d->ldw >= d->c_up + d->c_skip, "NULL argument / bad ldw");
+    if (d->c_up % 32 || d->c_skip % 32 || d->out_dim % 32 || d->ldw % 4 || ((uintptr_t)d->w & 15u))
+        return ws_fail(WS_ERR_UNSUPPORTED, "decoder step: widths must be multiples of 32 (c_up=%d c_skip=%d out=%d)", d->c_up, d->c_skip,
+                       d->out_dim);
+    return WS_OK;
+}
+
+int upunary_fwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
+{
+    float* up = ar.take<float>(d->nf * d->out_dim);
+    const int64_t tmp_bytes = max3(ws_gemm_xb_scratch_bytes(d->nc, d->c_up, d->out_dim), ws_gemm_xb_scratch_bytes(d->nf, d->c_skip, d->out_dim), 16);
+    void* tmp = ar.take<char>(tmp_bytes);
+    if (!run || d->nf == 0) return WS_OK;
+    if (d->nc > 0)
+        WS_TRY(ws_gemm_xb_epilogue_strided(d->xc, d->nc, d->c_up, d->c_up, d->w, 1, d->ldw, d->out_dim, nullptr, nullptr, 0, 0, 0.0f, d->yc,
+                                           d->out_dim, tmp, tmp_bytes, st));
+    WS_TRY(ws_closest_pool_fwd(d->yc, d->nc, d->out_dim, d->ups, d->nf, d->h_up, up, st));
+    return ws_gemm_xb_epilogue_strided(d->skip, d->nf, d->c_skip, d->c_skip, d->w + d->c_up, 1, d->ldw, d->out_dim, d->b, up, d->out_dim,
+                                       d->relu ? 1 : 0, d->slope, d->out, d->out_dim, tmp, tmp_bytes, st);
+}
+
+int upunary_bwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
+{
+    float* dz = ar.take<float>(d->nf * d->out_dim);
+    float* dyc = ar.take<float>(d->nc * d->out_dim);
+    float* dwt = ar.take<float>((int64_t)d->out_dim * (d->c_up > d->c_skip ? d->c_up : d->c_skip));
+    int64_t tmp_bytes = max3(ws_act_bwd_colsum_scratch_bytes(d->nf, d->out_dim), ws_gemm_xty_scratch_bytes(d->nf, d->out_dim, d->c_skip),
+                             ws_gemm_xty_scratch_bytes(d->nc, d->out_dim, d->c_up));
+    tmp_bytes = max3(tmp_bytes, ws_gemm_xb_scratch_bytes(d->nf, d->out_dim, d->c_skip), ws_gemm_xb_scratch_bytes(d->nc, d->out_dim, d->c_up));
+    void* tmp = ar.take<char>(tmp_bytes > 16 ? tmp_bytes : 16);
+    if (!run) return WS_OK;
+    WS_REQUIRE(d->dout && d->dw && d->dxc && d->dskip && d->t_offsets && d->t_pairs, "NULL gradient buffer / table");
+    const int64_t cw = d->c_up + d->c_skip;
+    if (d->nf == 0 || d->nc == 0) {
+        WS_HIP(hipMemsetAsync(d->dw, 0, sizeof(float) * (size_t)d->out_dim * cw, st));
+        if (d->db) WS_HIP(hipMemsetAsync(d->db, 0, sizeof(float) * d->out_dim, st));
+        if (d->nc > 0) WS_HIP(hipMemsetAsync(d->dxc, 0, sizeof(float) * (size_t)d->nc * d->c_up, st));
+        if (d->nf > 0) WS_HIP(hipMemsetAsync(d->dskip, 0, sizeof(float) * (size_t)d->nf * d->c_skip, st));
+        return WS_OK;
+    }
+    // dz = dout * lrelu'(out) (identity when !relu), db
+    const float* g = d->dout;
+    if (d->relu) {
+        WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, dz, d->out_dim, d->db, tmp, st));
+        g = dz;
+    } else if (d->db) {
+        WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, nullptr, 0, 0.0f, nullptr, 0, d->db, tmp, st));
+    }
+    // skip side
+    WS_TRY(ws_gemm_xty(g, d->nf, d->out_dim, d->out_dim, d->skip, d->c_skip, d->c_skip, dwt, tmp, st));
+    WS_HIP(hipMemcpy2DAsync(d->dw + d->c_up, sizeof(float) * cw, dwt, sizeof(float) * d->c_skip, sizeof(float) * d->c_skip, d->out_dim,
+                            hipMemcpyDeviceToDevice, st));
+    WS_TRY(ws_gemm_xb_epilogue_strided(g, d->nf, d->out_dim, d->out_dim, d->w + d->c_up, d->ldw, 1, d->c_skip, nullptr, nullptr, 0, 0, 0.0f,
+                                       d->dskip, d->c_skip, tmp, tmp_bytes, st));
+    // coarse side: nearest upsampling backward, then the x-part of the unary
+    WS_TRY(ws_closest_pool_bwd(g, d->nf, 1, d->out_dim, d->t_offsets, d->t_pairs, d->nc, dyc, st));
+    WS_TRY(ws_gemm_xty(dyc, d->nc, d->out_dim, d->out_dim, d->xc, d->c_up, d->c_up, dwt, tmp, st));
+    WS_HIP(hipMemcpy2DAsync(d->dw, sizeof(float) * cw, dwt, sizeof(float) * d->c_up, sizeof(float) * d->c_up, d->out_dim,
+                            hipMemcpyDeviceToDevice, st));
+    return ws_gemm_xb_epilogue_strided(dyc, d->nc, d->out_dim, d->out_dim, d->w, d->ldw, 1, d->c_up, nullptr, nullptr, 0, 0, 0.0f, d->dxc,
+                                       d->c_up, tmp, tmp_bytes, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ws_kpblock_fwd_scratch_bytes(const ws_kpblock* d)
+{
+    if (check_kpblock(d)) return -1;
+    Arena ar(nullptr, 0);
+    kpblock_fwd(d, ar, nullptr, false);
+    return ar.off + 256;
+}
+
+int64_t ws_kpblock_bwd_scratch_bytes(const ws_kpblock* d)
+{
+    if (check_kpblock(d)) return -1;
+    Arena ar(nullptr, 0);
+    kpblock_bwd(d, ar, nullptr, false);
+    return ar.off + 256;
+}
+
+int ws_kpblock_fwd(const ws_kpblock* d, void* scratch, int64_t scratch_bytes, void* stream)
+{
+    WS_TRY(check_kpblock(d));
+    WS_REQUIRE(scratch && ((uintptr_t)scratch & 15u) == 0, "scratch must be a 16-byte aligned device buffer");
+    Arena plan(nullptr, 0);
+    kpblock_fwd(d, plan, nullptr, false);
+    if (plan.off > scratch_bytes) return ws_fail(WS_ERR_CAPACITY, "scratch too small: %lld < %lld bytes", (long long)scratch_bytes, (long long)plan.off);
+    Arena ar(scratch, scratch_bytes);
+    return kpblock_fwd(d, ar, (hipStream_t)stream, true);
+}
+
+int ws_kpblock_bwd(const ws_kpblock* d, void* scratch, int64_t scratch_bytes, void* stream)
+{
+    WS_TRY(check_kpblock(d));
+    WS_REQUIRE(scratch && ((uintptr_t)scratch & 15u) == 0, "scratch must be a 16-byte aligned device buffer");
+    Arena plan(nullptr, 0);
+    kpblock_bwd(d, plan, nullptr, false);
+    if (plan.off > scratch_bytes) return ws_fail(WS_ERR_CAPACITY, "scratch too small: %lld < %lld bytes", (long long)scratch_bytes, (long long)plan.off);
+    Arena ar(scratch, scratch_bytes);
+    return kpblock_bwd(d, ar, (hipStream_t)stream, true);
+}
+
+int64_t ws_upunary_fwd_scratch_bytes(const ws_upunary* d)
+{
+    if (check_upunary(d)) return -1;
+    Arena ar(nullptr, 0);
+    upunary_fwd(d, ar, nullptr, false);
+    return ar.off + 256;
+}
+
+int64_t ws_upunary_bwd_scratch_bytes(const ws_upunary* d)
+{
+    if (check_upunary(d)) return -1;
+    Arena ar(nullptr, 0);
+    upunary_bwd(d, ar, nullptr, false);
+    return ar.off + 256;
+}
+
+int ws_upunary_fwd(const ws_upunary* d, void* scratch, int64_t scratch_bytes, void* stream)
+{
+    WS_TRY(check_upunary(d));
+    WS_REQUIRE(scratch && ((uintptr_t)scratch & 15u) == 0, "scratch must be a 16-byte aligned device buffer");
+    Arena plan(nullptr, 0);
+    upunary_fwd(d, plan, nullptr, false);
+    if (plan.off > scratch_bytes) return ws_fail(WS_ERR_CAPACITY, "scratch too small: %lld < %lld bytes", (long long)scratch_bytes, (long long)plan.off);
+    Arena ar(scratch, scratch_bytes);
+    return upunary_fwd(d, ar, (hipStream_t)stream, true);
+}
+
+int ws_upunary_bwd(const ws_upunary* d, void* scratch, int64_t scratch_bytes, void* stream)
+{
+    WS_TRY(check_upunary(d));
+    WS_REQUIRE(scratch && ((uintptr_t)scratch & 15u) == 0, "scratch must be a 16-byte aligned device buffer");
+    Arena plan(nullptr, 0);
+    upunary_bwd(d, plan, nullptr, false);
+    if (plan.off > scratch_bytes) return ws_fail(WS_ERR_CAPACITY, "scratch too small: %lld < %lld bytes", (long long)scratch_bytes, (long long)plan.off);
+    Arena ar(scratch, scratch_bytes);
+    return upunary_bwd(d, ar, (hipStream_t)stream, true);
+}
+
+int ws_timer_reset(void)
+{
+    for (auto& r : timer_recs()) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    timer_recs().clear();
+    return WS_OK;
+}
+
+int ws_timer_count(void) { return (int)timer_recs().size(); }
+
+int ws_timer_read(int32_t i, int64_t* nq, int32_t* h, int32_t* ci, float* ms)
+{
+    WS_REQUIRE(i >= 0 && i < (int)timer_recs().size() && nq && h && ci && ms, "bad timer record index %d", i);
+    const TimerRec& r = timer_recs()[i];
+    WS_HIP(hipEventSynchronize(r.b));
+    WS_HIP(hipEventElapsedTime(ms, r.a, r.b));
+    *nq = r.nq; *h = r.h; *ci = r.ci;
+    return WS_OK;
+}
+
+}  // extern "C"

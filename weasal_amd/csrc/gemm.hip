@@ -204,7 +204,7 @@ __device__ __forceinline__ void xb_rows_epilogue(const f32x16 (&acc)[NT], int64_
 // (valid memory, results never stored), so the main loop has no divergent control flow at all.
 template <int NT, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_xb2_kernel(
-    const float* __restrict__ x, int64_t m, int k, int64_t ldx, const float* __restrict__ b, int n, int ldb,
+    const float* __restrict__ x, int64_t m, int k, int64_t ldx, const float* __restrict__ b, int n, int ldb, int bcs,
     float* __restrict__ y, int64_t ldy, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldr,
     int act, float slope, int csplit, float* __restrict__ partial)
 {
@@ -237,7 +237,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     // buffer addressing (wave-uniform descriptors from kernel arguments / blockIdx, per-lane constant byte
     // offsets, the chunk advance in the scalar offset): no vector address arithmetic in the loop; rows of
     // X past m read as 0 through the bounds check
-    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, (int)((int64_t)k * ldb * 4), 0x00020000);
+    // B[kk][col] = b[kk * ldb + col * bcs]: bcs = 1 is the row-major [K,N] matrix, ldb = 1 with bcs = K' reads a
+    // row-major [N,K'] matrix as its transpose (nn.Linear's weight, or a weight's transpose in a backward) in place
+    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0,
+                                                        (int)(((int64_t)(k - 1) * ldb + (int64_t)(n - 1) * bcs + 1) * 4), 0x00020000);
     const int64_t brow0 = (int64_t)blockIdx.x * (32 * WM);
     const int64_t brows = m - brow0 < 32 * WM ? m - brow0 : 32 * WM;
     const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + brow0 * ldx), 0,
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
         const int c = g % BN, q = g / BN;
         int col = n0 + c;
         col = col < n ? col : n - 1;
-        woff[i] = (4 * q * ldb + col) * 4;
+        woff[i] = (4 * q * ldb + col * bcs) * 4;
         wlds[i] = ((((c >> 5) * 4 + (q >> 1)) * 2 + (q & 1)) * 32 + (c & 31)) * 4;
     }
     float4 wv[CT];
@@ -755,8 +758,10 @@ int64_t ws_gemm_xb_scratch_bytes(int64_t m, int32_t k, int32_t n)
 
 static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                         const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
-                        float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream)
+                        float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream,
+                        int64_t brs = -1, int64_t bcs = 1)
 {
+    if (brs < 0) brs = n;                       // row-major [K,N]
     WS_REQUIRE(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
     WS_REQUIRE(!residual || ldr >= n, "residual leading dimension too small");
     WS_REQUIRE(act == 0 || act == 1, "unknown activation %d", act);
@@ -768,8 +773,8 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
     const int64_t gx = ws_ceil_div(m, BM);
     WS_REQUIRE(gx < (1ll << 31), "m too large");
     if (ws_gemm_variant == 2 && vecx && k % 32 == 0 && n % 4 == 0 && al16(y) && ldy % 4 == 0 &&
-        (!residual || (al16(residual) && ldr % 4 == 0)) && (!bias || al16(bias)) && (int64_t)k * n < (1ll << 29) &&
-        128 * ldx < (1ll << 29)) {
+        (!residual || (al16(residual) && ldr % 4 == 0)) && (!bias || al16(bias)) &&
+        (int64_t)(k - 1) * brs + (int64_t)(n - 1) * bcs < (1ll << 29) && 128 * ldx < (1ll << 29)) {
 #define WS_XB2(NTV, WNV)                                                                                        \
     do {                                                                                                        \
         const unsigned gx2 = (unsigned)ws_ceil_div(m, 32 * (4 / WNV)), gy2 = (unsigned)ws_ceil_div(n, 32 * NTV * WNV); \
@@ -785,7 +790,7 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
         const int csplit = (int)ws_ceil_div(nch, splits);                                                       \
         splits = (int)ws_ceil_div(nch, csplit);                                                                 \
         float* part = splits > 1 ? (float*)scratch : nullptr;                                                   \
-        gemm_xb2_kernel<NTV, WNV><<<dim3(gx2, gy2, (unsigned)splits), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, bias, residual, \
+        gemm_xb2_kernel<NTV, WNV><<<dim3(gx2, gy2, (unsigned)splits), 256, 0, st>>>(x, m, k, ldx, b, n, (int)brs, (int)bcs, y, ldy, bias, residual, \
                                                                                     ldr, act, slope, csplit, part);         \
         if (splits > 1)                                                                                         \
             splitk_epilogue_kernel<<<ws_grid(m * (n / 4), 256), 256, 0, st>>>(part, splits, m, n, y, ldy, bias, residual, ldr, \
@@ -807,6 +812,8 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
         WS_LAUNCH_CHECK();
         return WS_OK;
     }
+    WS_REQUIRE(bcs == 1 && brs == n, "a strided small matrix needs k %% 32 == 0, n %% 4 == 0 and 16-byte aligned rows "
+                                     "(k=%d n=%d): pass a row-major [K,N] copy for this shape", k, n);
     if (n <= 32) {
         gemm_xb_kernel<1, 32><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
                                                                  act, slope);
@@ -872,6 +879,15 @@ int ws_gemm_xb_epilogue_splitk(const float* x, int64_t m, int32_t k, int64_t ldx
                                float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream)
 {
     return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream);
+}
+
+int ws_gemm_xb_epilogue_strided(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride,
+                                int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
+                                int32_t act, float slope, float* y, int64_t ldy, void* scratch, int64_t scratch_bytes,
+                                void* stream)
+{
+    return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
+                        b_row_stride, b_col_stride);
 }
 
 int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n, float* y, int64_t ldy,

@@ -641,9 +641,12 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, 
     hipStream_t st = (hipStream_t)stream;
     int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
     if (rc) { if (ws) ws->nq = 0; return rc; }
-    if ((rc = nb_launch_fill(ws, 128, width, out_i32, out_i64, true, st))) return rc;   // max-count word cleared by nb_prepare
+    // rows wider than the 128-entry fast path are asked for (deformable radius): sort slab of 2048 entries from the start,
+    // instead of a 128-entry pass the caller would have to repeat
+    const int cap = width > 128 ? 2048 : 128;
+    if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st))) return rc;   // max-count word cleared by nb_prepare
     WS_HIP(hipMemcpyAsync(d_max_count, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    ws->max_count_host = 128;   // unknown on the host; rows beyond 128 are reported through d_max_count
+    ws->max_count_host = cap;   // unknown on the host; rows beyond the slab are reported through d_max_count
     return WS_OK;
 }
 

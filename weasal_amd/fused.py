@@ -1,0 +1,323 @@
+"""Whole network blocks as ONE autograd node over ONE C call each way (ws_kpblock_fwd / _bwd, ws_upunary_fwd / _bwd,
+weasal_amd/csrc/blocks.hip).
+
+The reference runs a ResnetBottleneckBlock (models/blocks.py:624-709) as ~10 torch ops and as many autograd nodes;
+round 1 of this build ran it as 6 autograd.Function nodes with ~40 kernel launches issued from Python one by one
+(~11 ms of host time per step, more than most of those kernels take).  Here the block's forward is one call that
+launches its 6-7 kernels from C, its backward one call that launches 10-14; the gradient accumulations autograd used
+to add with separate kernels (shortcut + main branch into the block input) are residual operands of GEMM epilogues.
+Same arithmetic as weasal_amd.blocks' operator-by-operator path (same kernels, same order inside every sum), which
+stays in place for everything these calls do not cover (deformable / modulated KPConv, bf16 rows, non-linear influence,
+CPU oracle mode).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, current_stream
+
+FUSED_BLOCKS = os.environ.get("WEASAL_FUSED_BLOCKS", "1") != "0"      # A/B switch (diagnostics, tests)
+_timed = False
+
+
+def set_timed(on):
+    """bench.py: bracket every K3 launch inside the block calls with HIP events (ws_timer_*)"""
+    global _timed
+    _timed = bool(on)
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class KPBlockDesc(C.Structure):
+    """mirror of `struct ws_kpblock` (include/weasal_hip.h), field by field"""
+    _fields_ = [("q_pts", _vp), ("nq", _i64), ("s_pts", _vp), ("ns", _i64), ("inds", _vp), ("h", _i32),
+                ("kernel_points", _vp), ("k", _i32), ("extent", _f32), ("order_q", _vp), ("order_s", _vp),
+                ("grid_blob", _vp), ("grid_nb", _i32), ("grid_cells", _i64), ("key_last", _vp), ("grid_radius", _f32),
+                ("grid_overflow", _vp), ("t_offsets", _vp), ("t_pairs", _vp),
+                ("in_dim", _i32), ("conv_in", _i32), ("conv_out", _i32), ("out_dim", _i32), ("strided", _i32),
+                ("slope", _f32),
+                ("w1", _vp), ("b1", _vp), ("wk", _vp), ("bk", _vp), ("w2", _vp), ("b2", _vp), ("ws", _vp), ("bs", _vp),
+                ("feat", _vp), ("x1", _vp), ("wf", _vp), ("x2", _vp), ("pooled", _vp), ("arg", _vp), ("out", _vp),
+                ("dout", _vp), ("dfeat", _vp), ("dw1", _vp), ("db1", _vp), ("dwk", _vp), ("dbk", _vp), ("dw2", _vp),
+                ("db2", _vp), ("dws", _vp), ("timed", _i32)]
+
+
+class UpUnaryDesc(C.Structure):
+    """mirror of `struct ws_upunary`"""
+    _fields_ = [("xc", _vp), ("nc", _i64), ("c_up", _i32), ("skip", _vp), ("nf", _i64), ("c_skip", _i32),
+                ("ups", _vp), ("h_up", _i32), ("t_offsets", _vp), ("t_pairs", _vp),
+                ("w", _vp), ("ldw", _i64), ("b", _vp), ("out_dim", _i32), ("relu", _i32), ("slope", _f32),
+                ("yc", _vp), ("out", _vp), ("dout", _vp), ("dxc", _vp), ("dskip", _vp), ("dw", _vp), ("db", _vp)]
+
+
+def _bind():
+    return _lib.lib()          # signatures: _lib.SIGNATURES (descriptors travel as void* = ctypes.byref(struct))
+
+
+def timer_records():
+    """[(nq, h, ci, ms)] of the K3 launches timed inside the block calls since the last reset (synchronises)"""
+    lib = _bind()
+    out = []
+    nq, h, ci, ms = _i64(), _i32(), _i32(), _f32()
+    for i in range(lib.ws_timer_count()):
+        check(lib.ws_timer_read(i, C.byref(nq), C.byref(h), C.byref(ci), C.byref(ms)))
+        out.append((nq.value, h.value, ci.value, ms.value))
+    return out
+
+
+def timer_reset():
+    _bind().ws_timer_reset()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _scratch(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class _Geom:
+    """geometry + widths of one block call (plain Python object carried through the autograd node)"""
+    __slots__ = ("q_pts", "s_pts", "inds", "kp", "extent", "order_q", "order_s", "grid", "table", "in_dim", "conv_in",
+                 "conv_out", "out_dim", "strided", "slope", "has")
+
+    def fill(self, d):
+        d.q_pts, d.nq = self.q_pts.data_ptr(), self.q_pts.shape[0]
+        d.s_pts, d.ns = self.s_pts.data_ptr(), self.s_pts.shape[0]
+        d.inds, d.h = self.inds.data_ptr(), self.inds.shape[1]
+        d.kernel_points, d.k, d.extent = self.kp.data_ptr(), self.kp.shape[0], float(self.extent)
+        d.order_q, d.order_s = _p(self.order_q), _p(self.order_s)
+        if self.grid is not None:
+            g = self.grid
+            d.grid_blob, d.grid_nb, d.grid_cells = g.blob.data_ptr(), g.nb, g.cells
+            d.key_last, d.grid_radius, d.grid_overflow = g.key_last.data_ptr(), g.radius, g.overflow.data_ptr()
+        if self.table is not None:
+            d.t_offsets, d.t_pairs = self.table.offsets.data_ptr(), self.table.pairs.data_ptr()
+        d.in_dim, d.conv_in, d.conv_out, d.out_dim = self.in_dim, self.conv_in, self.conv_out, self.out_dim
+        d.strided, d.slope = 1 if self.strided else 0, float(self.slope)
+
+
+def _al(n):
+    return (n + 63) // 64 * 64
+
+
+class _KPBlockFn(torch.autograd.Function):
+    """[unary1 ->] KPConv -> bias -> LeakyReLU [-> unary2 + shortcut -> LeakyReLU] (blocks.py:510-564, 624-709)"""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, wk, bk, w2, b2, wsc, bsc, geom):
+        lib = _bind()
+        dev = feat.device
+        feat = feat.contiguous()
+        g = geom
+        nq, ns = g.q_pts.shape[0], g.s_pts.shape[0]
+        k = g.kp.shape[0]
+        # saved activations in ONE arena: x1 | wf | x2 | pooled | arg
+        sizes = [ns * g.conv_in if w1 is not None else 0, nq * k * g.conv_in, nq * g.conv_out if w2 is not None else 0,
+                 nq * g.in_dim if (g.strided and w2 is not None) else 0, nq * g.in_dim if (g.strided and w2 is not None) else 0]
+        offs, tot = [], 0
+        for s in sizes:
+            offs.append(tot)
+            tot += _al(s)
+        arena = torch.empty(max(tot, 64), dtype=torch.float32, device=dev)
+        base = arena.data_ptr()
+        out = torch.empty((nq, g.out_dim), dtype=torch.float32, device=dev)
+        d = KPBlockDesc()
+        g.fill(d)
+        wkc = wk.contiguous()
+        d.w1, d.b1, d.wk, d.bk, d.w2, d.b2, d.ws, d.bs = _p(w1), _p(b1), wkc.data_ptr(), _p(bk), _p(w2), _p(b2), _p(wsc), _p(bsc)
+        d.feat = feat.data_ptr()
+        d.x1 = base + 4 * offs[0] if sizes[0] else None
+        d.wf = base + 4 * offs[1]
+        d.x2 = base + 4 * offs[2] if sizes[2] else None
+        d.pooled = base + 4 * offs[3] if sizes[3] else None
+        d.arg = base + 4 * offs[4] if sizes[4] else None
+        d.out = out.data_ptr()
+        d.timed = 1 if _timed else 0
+        nbytes = lib.ws_kpblock_fwd_scratch_bytes(C.byref(d))
+        if nbytes < 0:
+            check(1)
+        scratch = _scratch(nbytes, dev)
+        check(lib.ws_kpblock_fwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
+        ctx.geom, ctx.offs, ctx.sizes = g, offs, sizes
+        ctx.save_for_backward(feat, arena, out, w1, b1, wkc, bk, w2, b2, wsc, bsc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _bind()
+        feat, arena, out, w1, b1, wk, bk, w2, b2, wsc, bsc = ctx.saved_tensors
+        g, offs, sizes = ctx.geom, ctx.offs, ctx.sizes
+        dev = feat.device
+        dout = dout.contiguous()
+        nq, ns = g.q_pts.shape[0], g.s_pts.shape[0]
+        need = ctx.needs_input_grad
+        d = KPBlockDesc()
+        g.fill(d)
+        d.w1, d.b1, d.wk, d.bk, d.w2, d.b2, d.ws, d.bs = _p(w1), _p(b1), wk.data_ptr(), _p(bk), _p(w2), _p(b2), _p(wsc), _p(bsc)
+        base = arena.data_ptr()
+        d.feat = feat.data_ptr()
+        d.x1 = base + 4 * offs[0] if sizes[0] else None
+        d.wf = base + 4 * offs[1]
+        d.x2 = base + 4 * offs[2] if sizes[2] else None
+        d.pooled = base + 4 * offs[3] if sizes[3] else None
+        d.arg = base + 4 * offs[4] if sizes[4] else None
+        d.out, d.dout = out.data_ptr(), dout.data_ptr()
+        dfeat = torch.empty_like(feat) if need[0] else None
+        d.dfeat = _p(dfeat)
+        # parameter gradients in one flat buffer
+        shapes = [None if w1 is None else w1.shape, None if b1 is None else b1.shape, wk.shape, None if bk is None else bk.shape,
+                  None if w2 is None else w2.shape, None if b2 is None else b2.shape, None if wsc is None else wsc.shape]
+        goffs, tot = [], 0
+        for s in shapes:
+            goffs.append(tot)
+            tot += _al(s.numel()) if s is not None else 0
+        flat = torch.empty(max(tot, 64), dtype=torch.float32, device=dev)
+        fb = flat.data_ptr()
+        ptrs = [fb + 4 * o if s is not None else None for o, s in zip(goffs, shapes)]
+        d.dw1, d.db1, d.dwk, d.dbk, d.dw2, d.db2, d.dws = ptrs
+        nbytes = lib.ws_kpblock_bwd_scratch_bytes(C.byref(d))
+        if nbytes < 0:
+            check(1)
+        scratch = _scratch(nbytes, dev)
+        check(lib.ws_kpblock_bwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
+        grads = [flat[o:o + s.numel()].view(s) if s is not None else None for o, s in zip(goffs, shapes)]
+        dw1, db1, dwk, dbk, dw2, db2, dws = grads
+        dbs = db2 if bsc is not None else None          # the shortcut bias sees the same dz as b2
+        return dfeat, dw1, db1, dwk, dbk, dw2, db2, dws, dbs, None
+
+
+def _conv_ok(conv, x):
+    return (FUSED_BLOCKS and x.is_cuda and x.dtype == torch.float32 and not conv.deformable and conv.K == 15
+            and conv.KP_influence == 'linear' and conv.aggregation_mode == 'sum' and ops.kpconv_gather is _KPCONV_GATHER)
+
+
+_KPCONV_GATHER = ops.kpconv_gather         # (oracle.kpconv_ref.cpu_reference_mode swaps ops.* : then the blocks run operator by operator)
+
+
+def _geometry(conv, q_pts, s_pts, inds, strided):
+    g = _Geom()
+    g.q_pts, g.s_pts = ops._f32c(q_pts), ops._f32c(s_pts)
+    inds = inds.contiguous()
+    g.inds = inds if inds.dtype == torch.int64 else inds.to(torch.int64)
+    g.kp, g.extent = conv.kernel_points, conv.KP_extent
+    g.order_q, g.order_s = ops._order_for(g.q_pts), ops._order_for(g.s_pts)
+    nq, ns = g.q_pts.shape[0], g.s_pts.shape[0]
+    self_query = nq == ns and g.q_pts.data_ptr() == g.s_pts.data_ptr()
+    grid = ops._grid_for(g.inds) if self_query else None
+    g.grid = grid if (grid is not None and grid.ns == ns) else None
+    g.table = None
+    g.strided = strided
+    return g
+
+
+def kpblock_eligible(block, x):
+    conv = block.KPConv
+    if not _conv_ok(conv, x):
+        return False
+    dims = [conv.out_channels]
+    if hasattr(block, "unary2"):
+        dims += [block.out_dim, block.in_dim, conv.in_channels]
+    return all(v % 4 == 0 for v in dims)
+
+
+def simple_block(block, x, batch, q_pts, s_pts, inds):
+    """SimpleBlock / SimpleBlock2 (blocks.py:510-622): KPConv -> BatchNormBlock bias -> LeakyReLU(0.1)"""
+    conv = block.KPConv
+    g = _geometry(conv, q_pts, s_pts, inds, 'strided' in block.block_name)
+    g.in_dim = g.conv_in = conv.in_channels
+    g.conv_out = g.out_dim = conv.out_channels
+    g.slope = 0.1
+    if x.requires_grad and g.grid is None:
+        g.table = ops.transposed_table(g.inds, g.s_pts.shape[0])
+    return _KPBlockFn.apply(x, None, None, conv.weights, block.batch_norm.epilogue_bias(), None, None, None, None, g)
+
+
+def resnetb_block(block, x, batch, q_pts, s_pts, inds):
+    """ResnetBottleneckBlock (blocks.py:624-709)"""
+    conv = block.KPConv
+    strided = 'strided' in block.block_name
+    g = _geometry(conv, q_pts, s_pts, inds, strided)
+    g.in_dim, g.conv_in, g.conv_out, g.out_dim = block.in_dim, conv.in_channels, conv.out_channels, block.out_dim
+    g.slope = 0.1
+    if g.grid is None or strided:
+        g.table = ops.transposed_table(g.inds, g.s_pts.shape[0])
+    u1 = block.unary1 if isinstance(block.unary1, torch.nn.Module) and hasattr(block.unary1, "mlp") else None
+    us = block.unary_shortcut if hasattr(block.unary_shortcut, "mlp") else None
+    return _KPBlockFn.apply(x,
+                            u1.mlp.weight if u1 is not None else None, u1.batch_norm.epilogue_bias() if u1 is not None else None,
+                            conv.weights, block.batch_norm_conv.epilogue_bias(),
+                            block.unary2.mlp.weight, block.unary2.batch_norm.epilogue_bias(),
+                            us.mlp.weight if us is not None else None, us.batch_norm.epilogue_bias() if us is not None else None,
+                            g)
+
+
+class _UpUnaryFn(torch.autograd.Function):
+    """nearest_upsample -> concat(skip) -> unary as up(x @ Wx^T) + skip @ Ws^T (architectures.py:339-343)"""
+
+    @staticmethod
+    def forward(ctx, xc, skip, w, b, ups, table, relu):
+        lib = _bind()
+        dev = xc.device
+        xc, skip, w = xc.contiguous(), skip.contiguous(), w.contiguous()
+        nc, c_up = xc.shape
+        nf, c_skip = skip.shape
+        out_dim = w.shape[0]
+        yc = torch.empty((max(nc, 1), out_dim), dtype=torch.float32, device=dev)
+        out = torch.empty((nf, out_dim), dtype=torch.float32, device=dev)
+        d = UpUnaryDesc()
+        d.xc, d.nc, d.c_up, d.skip, d.nf, d.c_skip = xc.data_ptr(), nc, c_up, skip.data_ptr(), nf, c_skip
+        d.ups, d.h_up = ups.data_ptr(), ups.shape[1]
+        d.w, d.ldw, d.b, d.out_dim, d.relu, d.slope = w.data_ptr(), w.stride(0), _p(b), out_dim, 1 if relu else 0, 0.1
+        d.yc, d.out = yc.data_ptr(), out.data_ptr()
+        nbytes = lib.ws_upunary_fwd_scratch_bytes(C.byref(d))
+        if nbytes < 0:
+            check(1)
+        scratch = _scratch(nbytes, dev)
+        check(lib.ws_upunary_fwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
+        ctx.table, ctx.relu = table, relu
+        ctx.save_for_backward(xc, skip, w, b, ups, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _bind()
+        xc, skip, w, b, ups, out = ctx.saved_tensors
+        dev = xc.device
+        dout = dout.contiguous()
+        nc, c_up = xc.shape
+        nf, c_skip = skip.shape
+        out_dim = w.shape[0]
+        d = UpUnaryDesc()
+        d.xc, d.nc, d.c_up, d.skip, d.nf, d.c_skip = xc.data_ptr(), nc, c_up, skip.data_ptr(), nf, c_skip
+        d.ups, d.h_up = ups.data_ptr(), ups.shape[1]
+        d.t_offsets, d.t_pairs = ctx.table.offsets.data_ptr(), ctx.table.pairs.data_ptr()
+        d.w, d.ldw, d.b, d.out_dim, d.relu, d.slope = w.data_ptr(), w.stride(0), _p(b), out_dim, 1 if ctx.relu else 0, 0.1
+        d.out, d.dout = out.data_ptr(), dout.data_ptr()
+        dxc, dskip = torch.empty_like(xc), torch.empty_like(skip)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b) if b is not None else None
+        d.dxc, d.dskip, d.dw, d.db = dxc.data_ptr(), dskip.data_ptr(), dw.data_ptr(), _p(db)
+        nbytes = lib.ws_upunary_bwd_scratch_bytes(C.byref(d))
+        if nbytes < 0:
+            check(1)
+        scratch = _scratch(nbytes, dev)
+        check(lib.ws_upunary_bwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
+        return dxc, dskip, dw, db, None, None, None
+
+
+def upunary_eligible(x, skip, unary):
+    return (FUSED_BLOCKS and x.is_cuda and x.dtype == torch.float32 and skip.dtype == torch.float32
+            and ops.kpconv_gather is _KPCONV_GATHER and x.shape[1] % 32 == 0 and skip.shape[1] % 32 == 0
+            and unary.out_dim % 32 == 0 and x.shape[0] > 0 and skip.shape[0] > 0)
+
+
+def upunary(x, skip, unary, ups):
+    ups = ups.contiguous()
+    ups = ups if ups.dtype == torch.int64 else ups.to(torch.int64)
+    table = ops.col0_table(ups, x.shape[0])
+    return _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, not unary.no_relu)

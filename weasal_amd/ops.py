@@ -97,6 +97,18 @@ def clear_table_cache():
 _col0_tables = {}     # (inds.data_ptr(), shape, ns) -> table of the first column (closest_pool backward)
 
 
+def col0_table(inds, ns):
+    """transposed table of the FIRST column of `inds` (closest_pool / nearest upsampling backward), cached per index
+    tensor like the full tables"""
+    key = (inds.data_ptr(), tuple(inds.shape), ns)
+    hit = _col0_tables.get(key)
+    if hit is not None:
+        return hit[1]
+    table = TransposedTable(inds[:, :1].contiguous(), ns)
+    _col0_tables[key] = (inds, table)
+    return table
+
+
 def install_tables(full, col0):
     """pre-built tables of a prefetched batch (PyramidBatch.activate): `full` = [(inds, ns, table)],
     `col0` = [(inds, ns, table of inds[:, :1])]"""
@@ -578,8 +590,7 @@ class _ClosestPool(torch.autograd.Function):
         check(_by_dtype(lib, "ws_closest_pool_fwd", x)(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), current_stream()))
         # only the first column takes part (blocks.py:92): the backward needs the transposed
         # table of that column alone (lists of ~N_fine/N_coarse entries instead of ~H times that)
-        ctx.key = (inds.data_ptr(), tuple(inds.shape), ns)
-        ctx.col0 = None if ctx.key in _col0_tables else inds[:, :1].contiguous()
+        ctx.table = col0_table(inds, ns)
         ctx.nq = nq
         ctx.ns = ns
         return out
@@ -589,14 +600,7 @@ class _ClosestPool(torch.autograd.Function):
         lib = _lib.lib()
         nq = ctx.nq
         c = dy.shape[1]
-        hit = _col0_tables.get(ctx.key)
-        if hit is not None:
-            table = hit[1]
-        else:
-            col0 = ctx.col0 if ctx.col0 is not None else None
-            if col0 is None:
-                raise _lib.WeasalHipError("closest_pool backward: the pre-built column-0 table was dropped before backward")
-            table = TransposedTable(col0, ctx.ns)
+        table = ctx.table
         dx = torch.empty((ctx.ns, c), dtype=dy.dtype, device=dy.device)
         dy = dy.contiguous()
         check(_by_dtype(lib, "ws_closest_pool_bwd", dy)(ptr(dy), nq, 1, c, ptr(table.offsets), ptr(table.pairs), ctx.ns, ptr(dx),
@@ -783,7 +787,7 @@ class DeferredSearches:
             q, s, ql, sl, radius, width = args
             if mc == 0:
                 raise _lib.WeasalHipError("libweasal_hip status 4: Error")
-            if mc > 128:
+            if mc > (2048 if width > 128 else 128):      # beyond the sort slab the asynchronous pass used
                 out = radius_neighbors(q, s, ql, sl, radius, limit=width, dtype=torch.int64)
             elif mc < width:
                 out = out[:, :int(mc)].contiguous()

@@ -8,10 +8,15 @@ import numpy as np
 WORKLOADS = {
     "dales": dict(config="DALESPLConfig", radius=10.0, points=50000, spheres=8, limits=[59, 73, 81, 77, 56],
                   name="DALES_PseudoLabel KP-FCNN, in_radius=10m, 50k pts/sphere, batch=8"),
-    # config 5 shape in fp32: deformable + modulated KPConv in the two deepest levels (their searches use the
-    # deformable radius = 2 x the rigid one: about 8 x the neighbours, limits from the same 90th-percentile rule)
-    "dales_deform": dict(config="DALESDeformConfig", radius=10.0, points=50000, spheres=8, limits=[59, 73, 81, 420, 260],
-                         name="DALES deformable + modulated KP-FCNN (fp32), in_radius=10m, 50k pts/sphere, batch=8"),
+    # BASELINE config 5 as SURVEY 8d specifies it: every resnetb block deformable + modulated, so every level is searched
+    # with the deformable radius (2 x the rigid one: about 8 x the neighbours); limits = the same 90th-percentile rule
+    # measured on this distribution with the CPU oracle (422 / 519 / 472, then every point of the two small levels)
+    "dales_deform": dict(config="DALESDeformConfig", radius=10.0, points=50000, spheres=8, limits=[422, 519, 472, 193, 34],
+                         name="DALES deformable + modulated KP-FCNN (every resnetb deformable, deform_radius 5.0), "
+                              "in_radius=10m, 50k pts/sphere, batch=8"),
+    "dales_deform_f32": dict(config="DALESDeformF32Config", radius=10.0, points=50000, spheres=8, limits=[422, 519, 472, 193, 34],
+                             name="DALES deformable + modulated KP-FCNN in f32 rows (A/B of the bf16 path), "
+                                  "in_radius=10m, 50k pts/sphere, batch=8"),
     "vaihingen": dict(config="Vaihingen3DPLConfig", radius=4.0, points=3000, spheres=4, limits=[],
                       name="Vaihingen3D_PseudoLabel KP-FCNN, in_radius=4m, 3k pts/sphere, batch=4"),
 }
