@@ -16,8 +16,10 @@ Tolerances held (max|a-b| / max|ref| per tensor), and why:
     so rounding enters the geometry):   out 2e-2; parameter gradients (sums over all points) 5e-2.  The gradient with
     respect to the kernel-point positions is DISCONTINUOUS where a neighbour crosses the influence extent
     (d w / d kp jumps from -(kp - n)/(extent |kp - n|) to 0, models/blocks.py:337), so a 1e-2 perturbation of the
-    offsets flips isolated neighbours and changes isolated entries of dx by O(10 %): dx is held in the relative
-    Frobenius norm (5e-2) with a loose max-norm guard (0.25)
+    offsets (what the bf16-row offset convolution delivers) flips the fraction 3 * 1e-2 * max|kp| / extent ~ 4 % of the
+    boundary terms: the gradients that flow through the offsets (dx, d offset weights / bias) are held at 0.12 with
+    `linear` influence (measured 0.05-0.07) -- and at 3e-2 with the smooth `gaussian` influence, which has no such
+    jump and therefore pins the bf16 arithmetic of that chain itself
   * pooling: bit-exact (max / copy of bf16 values).
 Integer outputs (neighbours, subsampling) are untouched by the feature dtype.
 """
@@ -142,15 +144,15 @@ def test_rigid_kpconv_bf16_vs_oracle(gpu, ci, co):
     assert rel(conv.weights.grad, twin.weights.grad) < 2e-2
 
 
-@pytest.mark.parametrize("modulated", [False, True])
-def test_deformable_kpconv_bf16_vs_oracle(gpu, modulated):
+@pytest.mark.parametrize("modulated,influence", [(False, "linear"), (True, "linear"), (True, "gaussian")])
+def test_deformable_kpconv_bf16_vs_oracle(gpu, modulated, influence):
     """deformable (+ modulated) KPConv, models/blocks.py:244-325,366-367: bf16 rows, f32 offsets / geometry"""
     import types
     from oracle import kpconv_ref
     from weasal_amd.architectures import p2p_fitting_regularizer
     ci, co = 32, 64
     P, inds = _geometry(gpu, radius=1.2, seed=3)
-    conv, twin = _layer_pair(gpu, ci, co, 0.36, 0.9, deformable=True, modulated=modulated)
+    conv, twin = _layer_pair(gpu, ci, co, 0.36, 0.9, deformable=True, modulated=modulated, KP_influence=influence)
     torch.manual_seed(4)
     x = torch.randn(P.shape[0], ci, device=gpu).to(BF)
     dy = torch.randn(P.shape[0], co, device=gpu).to(BF)
@@ -176,8 +178,9 @@ def test_deformable_kpconv_bf16_vs_oracle(gpu, modulated):
             "dW_off": rel(conv.offset_conv.weights.grad, twin.offset_conv.weights.grad),
             "db_off": rel(conv.offset_bias.grad, twin.offset_bias.grad)}
     print("bf16 deformable gradient errors:", errs)
-    assert errs["dx_l2"] < 5e-2 and errs["dx_max"] < 0.25, errs
-    assert errs["dW"] < 5e-2 and errs["dW_off"] < 5e-2 and errs["db_off"] < 5e-2, errs
+    tol = 0.12 if influence == "linear" else 3e-2
+    assert errs["dx_l2"] < tol and errs["dx_max"] < 2.5 * tol, errs
+    assert errs["dW"] < 3e-2 and errs["dW_off"] < tol and errs["db_off"] < tol, errs
 
 
 def test_pools_bf16_bit_exact(gpu):

@@ -258,7 +258,7 @@ int check_upunary(const ws_upunary* d)
 {
     WS_REQUIRE(d, "NULL descriptor");
     WS_REQUIRE(d->nc >= 0 && d->nf >= 0 && d->c_up >= 1 && d->c_skip >= 1 && d->out_dim >= 1 && d->h_up >= 1, "bad sizes");
-    WS_REQUIRE(d->xc && d->skip && d->ups && d->w && d->yc && d->out && d->ldw >= d->c_up + d->c_skip, "NULL argument / bad ldw");
+    WS_REQUIRE(d->xc && d->skip && d->ups && d->w && d->out && d->ldw >= d->c_up + d->c_skip, "NULL argument / bad ldw");
     if (d->c_up % 32 || d->c_skip % 32 || d->out_dim % 32 || d->ldw % 4 || ((uintptr_t)d->w & 15u))
         return ws_fail(WS_ERR_UNSUPPORTED, "decoder step: widths must be multiples of 32 (c_up=%d c_skip=%d out=%d)", d->c_up, d->c_skip,
                        d->out_dim);
@@ -271,6 +271,7 @@ int upunary_fwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
     const int64_t tmp_bytes = max3(ws_gemm_xb_scratch_bytes(d->nc, d->c_up, d->out_dim), ws_gemm_xb_scratch_bytes(d->nf, d->c_skip, d->out_dim), 16);
     void* tmp = ar.take<char>(tmp_bytes);
     if (!run || d->nf == 0) return WS_OK;
+    WS_REQUIRE(d->yc, "yc buffer missing");
     if (d->nc > 0)
         WS_TRY(ws_gemm_xb_epilogue_strided(d->xc, d->nc, d->c_up, d->c_up, d->w, 1, d->ldw, d->out_dim, nullptr, nullptr, 0, 0, 0.0f, d->yc,
                                            d->out_dim, tmp, tmp_bytes, st));
