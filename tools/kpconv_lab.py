@@ -1,0 +1,62 @@
+"""A/B of the K3 forward forms on DALES-shaped layers (interleaved rounds in one process, HIP events):
+variant 1 = entry pool + VALU accumulate, variant 2 = matrix core (ws_kpconv_variant).  Also checks that the two forms
+agree bit for bit.  Usage: python tools/kpconv_lab.py [rounds]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from weasal_amd import _lib, config as wcfg, ops, pyramid, synthetic  # noqa: E402
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    variant = C.c_int.in_dll(lib, "ws_kpconv_variant")
+    wl = synthetic.WORKLOADS["dales"]
+    cfg = wcfg.DALESPLConfig()
+    pts, feats, labels, lens = synthetic.make_inputs(1, wl["spheres"], wl["points"], wl["radius"], cfg.in_features_dim)
+    np.random.seed(0)
+    batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev),
+                                torch.from_numpy(labels).to(dev), lens, wl["limits"])
+    batch.activate()
+    kp = torch.from_numpy(np.load(os.path.join(os.path.dirname(ops.__file__), "data", "k_015_center_3D.npy")).astype(np.float32)).to(dev)
+    cases = [(0, 3, "enc0"), (0, 32, "enc1"), (1, 64, "enc3"), (2, 128, "enc5"), (3, 256, "enc7"), (4, 512, "enc9")]
+    for dt in (torch.float32, torch.bfloat16):
+        for lvl, ci, name in cases:
+            if dt == torch.bfloat16 and ci < 8:
+                continue
+            P = batch.points[lvl]
+            inds = batch.neighbors[lvl]
+            r = cfg.first_subsampling_dl * cfg.conv_radius * 2 ** lvl
+            extent = r * cfg.KP_extent / cfg.conv_radius
+            x = torch.randn(P.shape[0], ci, device=dev).to(dt)
+            kps = kp * r
+            outs, times = {}, {1: [], 2: []}
+            for rd in range(rounds):
+                for v in (1, 2):
+                    variant.value = v
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    wf, _ = ops.kpconv_gather(x, P, P, inds, kps, extent)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    times[v].append(e0.elapsed_time(e1))
+                    outs[v] = wf
+            variant.value = 2
+            same = torch.equal(outs[1], outs[2])
+            md = (outs[1].float() - outs[2].float()).abs().max().item()
+            n, h = inds.shape
+            es = 2 if dt == torch.bfloat16 else 4
+            b = n * h * (8 + 12 + es * ci) + n * (12 + es * ci) + 60 * ci * ci + 180
+            t1, t2 = np.median(times[1]), np.median(times[2])
+            print("%-5s %-8s N=%7d H=%3d Ci=%3d  pool %.4f ms (%.2f TB/s)  mfma %.4f ms (%.2f TB/s = %.2f of 8 TB/s)  bit-equal %s maxdiff %.2e"
+                  % (name, str(dt).split(".")[1], n, h, ci, t1, b / t1 / 1e9, t2, b / t2 / 1e9, b / t2 / 1e9 / 8.0, same, md), flush=True)
+
+
+if __name__ == "__main__":
+    main()

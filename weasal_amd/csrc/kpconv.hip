@@ -466,6 +466,249 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3 forward on the matrix core.  The weighted-feature product of the reference,
+//     weighted_features = torch.matmul(all_weights [N,K,H], neighb_x [N,H,Ci])       (models/blocks.py:363)
+// is a small dense matrix product per query: wf[q] (15 x Ci) = W_q^T (15 x H) . X_q (H x Ci).  Here it runs as such on
+// v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, so the sum over the neighbour columns has the same bits as
+// the per-kernel-point VALU chains of kpconv_gather_fwd_kernel -- zero weights add exactly nothing):
+//   A operand  A[i][k]   lane (i = lane&15, kk = lane>>4) holds the influence of kernel point i on neighbour column
+//              4 s + kk of step s: ONE weight, computed by that lane from the neighbour's offset (an LDS broadcast of
+//              the staged float4) and its own kernel point (rigid: a register for the whole launch; deformed: 3 loads
+//              per query).  No ballot, no compaction, no entry pool: 16 steps x ~10 VALU per 64 columns.
+//   B operand  B[k][j]   lane (j = lane&15, kk) loads NT consecutive channels of row inds[q, 4 s + kk] (one 4..64-byte
+//              load; the 16 lanes of a row cover 16 NT channels = the whole row for Ci <= 256), tile t = channel
+//              NT j + t; loads of a whole group of steps are in flight before the first MFMA needs them.
+//   C / D      lane (j, g = lane>>4) ends with kernel points 4 g .. 4 g + 3 of channels NT j .. NT j + NT - 1: rows of wf
+//              are written as contiguous 16 NT-channel runs.
+// Wider rows (H > 64) simply keep accumulating over further 64-column chunks: no read-modify-write of wf.  Only ~1.3 of
+// the 15 influences per neighbour are non-zero, so the matrix core does ~12 x the useful flops -- on a pipe that is
+// otherwise idle here, at 32 cycles per 16x16x4 step: 30 MFMAs per query at Ci = 32 against the ~750 VALU/SALU/LDS
+// instructions of the pool form.  MODE / DEF as above (MODE 0 = rigid, linear, sum).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int NT, typename T> struct RowLoad;
+template <int NT> struct RowLoad<NT, float> {
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[NT])
+    {
+        if constexpr (NT == 1) v[0] = *p;
+        else if constexpr (NT == 2) { const float2 a = *reinterpret_cast<const float2*>(p); v[0] = a.x; v[1] = a.y; }
+        else {
+#pragma unroll
+            for (int t = 0; t < NT; t += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(p + t);
+                v[t] = a.x; v[t + 1] = a.y; v[t + 2] = a.z; v[t + 3] = a.w;
+            }
+        }
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[NT])
+    {
+        if constexpr (NT == 1) *p = v[0];
+        else if constexpr (NT == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+        else {
+#pragma unroll
+            for (int t = 0; t < NT; t += 4) *reinterpret_cast<float4*>(p + t) = make_float4(v[t], v[t + 1], v[t + 2], v[t + 3]);
+        }
+    }
+};
+template <int NT> struct RowLoad<NT, bf16_t> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[NT])
+    {
+        if constexpr (NT == 1) v[0] = ld1(p);
+        else if constexpr (NT == 2) { const unsigned a = *reinterpret_cast<const unsigned*>(p); v[0] = ws_bf_lo(a); v[1] = ws_bf_hi(a); }
+        else if constexpr (NT == 4) { const float4 a = ld4(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+        else {
+#pragma unroll
+            for (int t = 0; t < NT; t += 8) {
+                const uint4 a = *reinterpret_cast<const uint4*>(p + t);
+                v[t] = ws_bf_lo(a.x); v[t + 1] = ws_bf_hi(a.x); v[t + 2] = ws_bf_lo(a.y); v[t + 3] = ws_bf_hi(a.y);
+                v[t + 4] = ws_bf_lo(a.z); v[t + 5] = ws_bf_hi(a.z); v[t + 6] = ws_bf_lo(a.w); v[t + 7] = ws_bf_hi(a.w);
+            }
+        }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[NT])
+    {
+        if constexpr (NT == 1) st1(p, v[0]);
+        else if constexpr (NT == 2) *reinterpret_cast<unsigned*>(p) = ws_pack_bf2(v[0], v[1]);
+        else if constexpr (NT == 4) st4(p, make_float4(v[0], v[1], v[2], v[3]));
+        else {
+#pragma unroll
+            for (int t = 0; t < NT; t += 8)
+                *reinterpret_cast<uint4*>(p + t) = make_uint4(ws_pack_bf2(v[t], v[t + 1]), ws_pack_bf2(v[t + 2], v[t + 3]),
+                                                              ws_pack_bf2(v[t + 4], v[t + 5]), ws_pack_bf2(v[t + 6], v[t + 7]));
+        }
+    }
+};
+
+// VECROW: ci is a multiple of NT and rows are aligned for NT-element accesses (else NT == 1 with per-lane masking)
+template <int NT, int MODE, bool DEF, bool VECROW, typename T>
+__global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
+    const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
+    const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci,
+    const float* __restrict__ kernel_points, const float* __restrict__ deformed_kp,
+    const float* __restrict__ modulations, GeomParams g, T* __restrict__ wf,
+    float* __restrict__ min_d2, const int32_t* __restrict__ order)
+{
+    constexpr int K = 15;
+    constexpr int CB = 16 * NT;                                   // channels per block
+    constexpr int GS = NT <= 2 ? 8 : (NT == 4 ? 4 : (NT == 8 ? 2 : 1));   // steps whose loads are in flight together
+    static_assert(!(DEF && MODE == 0), "deformable layers use MODE 1");
+    static_assert(VECROW || NT == 1, "masked rows use one channel per lane");
+    __shared__ float4 nb_all[4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kk = lane >> 4;                      // A: kernel point i; B / D: channel lane j = i; row group kk
+    float4* nb = nb_all[wave];
+    const float inv_extent = 1.0f / g.extent;
+    const float e2 = g.extent * g.extent;
+    const bool haskp = i < K;
+
+    int64_t ibeg, iend;
+    ws_block_range(nq, ibeg, iend);
+
+    float kx = 0.f, ky = 0.f, kz = 0.f;
+    if (!DEF && haskp) { kx = kernel_points[3 * i]; ky = kernel_points[3 * i + 1]; kz = kernel_points[3 * i + 2]; }
+
+    auto item_q = [&](int64_t it) -> int64_t { return it < iend ? (order ? (int64_t)order[it] : it) : -1; };
+    auto load_idx = [&](int64_t q, int col) -> int {
+        if (q < 0 || col >= h) return -1;
+        const int64_t v = inds[q * h + col];
+        return (v >= 0 && v < ns) ? (int)v : -1;
+    };
+    auto load_pt = [&](int idx, float& px, float& py, float& pz) {
+        px = py = pz = WS_SHADOW;
+        if (idx >= 0) { px = s_pts[3 * (int64_t)idx]; py = s_pts[3 * (int64_t)idx + 1]; pz = s_pts[3 * (int64_t)idx + 2]; }
+    };
+    // software pipeline over the items of this wave: indices two items ahead, coordinates one item ahead
+    int64_t q0 = item_q(ibeg + wave), q1 = item_q(ibeg + wave + 4);
+    int idx0 = load_idx(q0, lane), idx1 = load_idx(q1, lane);
+    float p0x, p0y, p0z;
+    load_pt(idx0, p0x, p0y, p0z);
+
+    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+        const int64_t q = q0;
+        const int64_t q2 = item_q(item + 8);
+        const int idx2 = load_idx(q2, lane);
+        float p1x, p1y, p1z;
+        load_pt(idx1, p1x, p1y, p1z);
+        const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
+        if (DEF && haskp) {
+            const float* kp = deformed_kp + q * (3 * K) + 3 * i;
+            kx = kp[0]; ky = kp[1]; kz = kp[2];
+        }
+        float mind = 3.4e38f;
+        for (int cb = 0; cb < ci; cb += CB) {
+            f32x4v acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            const int ch = cb + NT * i;                           // first channel of this lane
+            const bool chok = VECROW ? (ch < ci) : (ch < ci);
+            for (int h0 = 0; h0 < h; h0 += 64) {
+                int idx = idx0;
+                float px = p0x, py = p0y, pz = p0z;
+                if (h0 > 0) {
+                    idx = load_idx(q, h0 + lane);
+                    load_pt(idx, px, py, pz);
+                }
+                wave_lds_sync();                                  // the previous chunk's readers are done
+                nb[lane] = make_float4(px - qx, py - qy, pz - qz, __int_as_float((h0 + lane < h) ? (idx >= 0 ? idx : -2) : -1));
+                wave_lds_sync();
+                const int cols = min(64, h - h0);
+                const int steps = (cols + 3) >> 2;
+                float wb[2][GS];
+                float xb[2][GS][NT];
+                auto load_group = [&](int gi, int slot) {
+#pragma unroll
+                    for (int u = 0; u < GS; ++u) {
+                        const int s = gi * GS + u;
+                        const float4 n = nb[min(4 * s + kk, 63)];
+                        const int nidx = __float_as_int(n.w);     // >= 0 real, -2 shadow column, -1 past the row
+                        const bool live = nidx >= 0 && s < steps;
+                        const unsigned row = live ? (unsigned)nidx : 0u;
+                        const T* src = x + (size_t)(row * (unsigned)ci) + (chok ? ch : 0);
+                        RowLoad<NT, T>::ld(src, xb[slot][u]);
+                        // influence of this lane's kernel point on that neighbour
+                        const float dx = n.x - kx, dy = n.y - ky, dz = n.z - kz;
+                        const float d2 = (dx * dx + dy * dy) + dz * dz;
+                        float w;
+                        if (MODE == 0) {
+                            w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.0f);
+                        } else {
+                            w = kp_weight(d2, g, inv_extent);
+                            if (g.aggregation == WS_AGGREGATION_CLOSEST) {
+                                // arg-min kernel point of this neighbour over the 16 lanes of the row group (first wins)
+                                float bd = haskp ? d2 : 3.4e38f;
+                                int bi = i;
+#pragma unroll
+                                for (int o = 1; o < 16; o <<= 1) {
+                                    const float od = __shfl_xor(bd, o, 64);
+                                    const int oi = __shfl_xor(bi, o, 64);
+                                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                                }
+                                if (bi != i) w = 0.0f;
+                            }
+                            if (DEF) {
+                                const unsigned long long m = __ballot(haskp && d2 < e2);
+                                if ((((unsigned)(m >> (16 * kk))) & 0xffffu) == 0u) w = 0.0f;     // no kernel point in range (blocks.py:301-325)
+                                if (nidx != -1 && s < steps && haskp) mind = fminf(mind, d2);
+                            }
+                        }
+                        wb[slot][u] = (live && haskp) ? w : 0.0f;
+                        if (!chok) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) xb[slot][u][t] = 0.0f;
+                        }
+                    }
+                };
+                auto comp_group = [&](int slot) {
+#pragma unroll
+                    for (int u = 0; u < GS; ++u)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[slot][u], xb[slot][u][t], acc[t], 0, 0, 0);
+                };
+                const int ngroups = (steps + GS - 1) / GS;
+                load_group(0, 0);
+                for (int gi = 0; gi < ngroups; gi += 2) {
+                    if (gi + 1 < ngroups) load_group(gi + 1, 1);
+                    comp_group(0);
+                    if (gi + 1 < ngroups) {
+                        if (gi + 2 < ngroups) load_group(gi + 2, 0);
+                        comp_group(1);
+                    }
+                }
+            }
+            // D: lane (j = i, g = kk) holds kernel points 4 kk + r of its NT channels
+            if (chok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * kk + r;
+                    if (k < K) {
+                        float v[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) v[t] = acc[t][r];
+                        if (modulations) {
+                            const float md = modulations[q * K + k];
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) v[t] *= md;
+                        }
+                        RowLoad<NT, T>::st(wf + (q * K + k) * ci + ch, v);
+                    }
+                }
+            }
+        }
+        if (DEF && min_d2) {
+            mind = fminf(mind, __shfl_xor(mind, 16, 64));
+            mind = fminf(mind, __shfl_xor(mind, 32, 64));
+            if (kk == 0 && haskp) min_d2[q * K + i] = mind;
+        }
+        q0 = q1; q1 = q2;
+        idx0 = idx1; idx1 = idx2;
+        p0x = p1x; p0y = p1y; p0z = p1z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4 backward w.r.t. x through the transposed table: dx[s, :] = sum_e weight_e * dwf[row_e, :]
 // with row_e = q*K + k.  One wave per support; the flush is balanced over the S slots
 // (slot s takes entries [s*per, (s+1)*per)) and the S partial sums are combined by shuffles.
@@ -946,6 +1189,15 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
 }
 
 
+}  // namespace
+
+// 1 = entry pool + VALU accumulate (kpconv_gather_fwd_kernel), 2 = matrix core (kpconv_gather_fwd_mfma_kernel);
+// diagnostic switch (tools / A-B tests), not part of the drop-in surface
+extern "C" int ws_kpconv_variant;
+int ws_kpconv_variant = 2;
+
+namespace {
+
 template <typename T>
 int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
                     const int64_t* inds, int32_t h, const T* x, int32_t ci,
@@ -964,6 +1216,33 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
     WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(x) && ws_row_aligned<T>(wf);
     WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
+    if (ws_kpconv_variant == 2) {
+        // matrix-core form (kpconv_gather_fwd_mfma_kernel): NT consecutive channels per lane, 16 NT channels per block
+        const bool fastm = !deformed_kp && !modulations && influence == WS_INFLUENCE_LINEAR && aggregation == WS_AGGREGATION_SUM;
+        int nt = ci <= 16 ? 1 : (ci <= 32 ? 2 : (ci <= 64 ? 4 : (ci <= 128 ? 8 : 16)));
+        const bool al16 = aligned16(x) && aligned16(wf);
+        bool vecrow = (ci % nt == 0) && (nt == 1 || al16);
+        if (!vecrow) nt = 1;
+        if (nt == 1) vecrow = true;       // one channel per lane: any ci, any alignment (lanes past ci are masked)
+#define WS_FWDM2(NTV, MODEV, DEFV)                                                                                  \
+    kpconv_gather_fwd_mfma_kernel<NTV, MODEV, DEFV, true, T><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, \
+                                                                                   kernel_points, deformed_kp, modulations, g, wf, min_d2, order)
+#define WS_FWDM(NTV)                                    \
+    do {                                                \
+        if (deformed_kp) WS_FWDM2(NTV, 1, true);        \
+        else if (fastm) WS_FWDM2(NTV, 0, false);        \
+        else WS_FWDM2(NTV, 1, false);                   \
+    } while (0)
+        if (nt == 1) WS_FWDM(1);
+        else if (nt == 2) WS_FWDM(2);
+        else if (nt == 4) WS_FWDM(4);
+        else if (nt == 8) WS_FWDM(8);
+        else WS_FWDM(16);
+#undef WS_FWDM
+#undef WS_FWDM2
+        WS_LAUNCH_CHECK();
+        return WS_OK;
+    }
 #define WS_FWD2(G, MODEV, DEFV, VECV)                                                                              \
     do {                                                                                                           \
         if constexpr (F32 || VECV)                                                                                 \
