@@ -247,10 +247,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
                                                         (int)(((brows - 1) * ldx + k) * 4), 0x00020000);
     int woff[CT];
     int wlds[CT];
+    // transposed-in-place small matrix (ldb == 1): the four k of a row quad are 16 contiguous bytes and the 8 quads of a
+    // chunk one 128-byte line per column -> lanes run along k (8 lanes per column, one dwordx4 each: 8 whole lines per wave
+    // instruction); row-major: lanes run along the columns, four dword loads one row apart
+    const bool wtr = ldb == 1;
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
         const int g = t + 256 * i;
-        const int c = g % BN, q = g / BN;
+        const int c = wtr ? g / 8 : g % BN, q = wtr ? g % 8 : g / BN;
         int col = n0 + c;
         col = col < n ? col : n - 1;
         woff[i] = (4 * q * ldb + col * bcs) * 4;
@@ -259,6 +263,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     float4 wv[CT];
     auto load_w = [&](int chunk) {
         const int so = chunk * KC * ldb * 4;                       // uniform byte offset of the chunk
+        if (wtr) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wsrd, woff[i], so, 0);
+                wv[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             wv[i].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrd, woff[i], so, 0));
@@ -774,7 +786,8 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
     WS_REQUIRE(gx < (1ll << 31), "m too large");
     if (ws_gemm_variant == 2 && vecx && k % 32 == 0 && n % 4 == 0 && al16(y) && ldy % 4 == 0 &&
         (!residual || (al16(residual) && ldr % 4 == 0)) && (!bias || al16(bias)) &&
-        (int64_t)(k - 1) * brs + (int64_t)(n - 1) * bcs < (1ll << 29) && 128 * ldx < (1ll << 29)) {
+        (int64_t)(k - 1) * brs + (int64_t)(n - 1) * bcs < (1ll << 29) && 128 * ldx < (1ll << 29) && al16(b) &&
+        (bcs == 1 ? true : (brs == 1 && bcs % 4 == 0))) {
 #define WS_XB2(NTV, WNV)                                                                                        \
     do {                                                                                                        \
         const unsigned gx2 = (unsigned)ws_ceil_div(m, 32 * (4 / WNV)), gy2 = (unsigned)ws_ceil_div(n, 32 * NTV * WNV); \
