@@ -14,6 +14,7 @@ from weasal_amd import _lib, config as wcfg, ops, pyramid, synthetic  # noqa: E4
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    only = sys.argv[2] if len(sys.argv) > 2 else None          # e.g. "enc1": one layer, f32 only (counter runs)
     dev = torch.device("cuda:0")
     lib = _lib.lib()
     variant = C.c_int.in_dll(lib, "ws_kpconv_variant")
@@ -29,6 +30,8 @@ def main():
     for dt in (torch.float32, torch.bfloat16):
         for lvl, ci, name in cases:
             if dt == torch.bfloat16 and ci < 8:
+                continue
+            if only is not None and (name != only or dt != torch.float32):
                 continue
             P = batch.points[lvl]
             inds = batch.neighbors[lvl]
