@@ -219,6 +219,9 @@ def main():
                 i += 1
         prefetcher = PyramidPrefetcher(cfg, endless(), wl["limits"], depth=2, device=dev)
 
+    from weasal_amd.trainer import InFlightLimiter
+    limiter = InFlightLimiter(depth=4)
+
     def step(i):
         if prefetcher is not None:
             batch = next(prefetcher)
@@ -226,6 +229,7 @@ def main():
             pts, feats, labels, lens = inputs[i % nd]
             batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
         loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync, epoch=0 if args.contrast else None)
+        limiter.tick(batch)          # bounds the host's run-ahead (4 steps); checks the K4G capacity flags off the hot path
         return loss
 
     # Untimed pre-warm before the W warm-up steps (allocator caches, lazy module loads), then the training

@@ -22,6 +22,7 @@ def _run(gpu, cfg, fused_on, seed=3, steps=1):
     from weasal_amd.architectures import KPFCNN
     from weasal_amd.trainer import make_optimizer, train_step
     fused.FUSED_BLOCKS = fused_on
+    min_rows, fused.MIN_ROWS = fused.MIN_ROWS, 0          # every block through the calls (the product keeps layers < 4096 rows on the operator path)
     try:
         np.random.seed(seed)
         torch.manual_seed(seed)
@@ -39,6 +40,7 @@ def _run(gpu, cfg, fused_on, seed=3, steps=1):
         return out.detach().clone(), loss.item(), grads, params
     finally:
         fused.FUSED_BLOCKS = True
+        fused.MIN_ROWS = min_rows
 
 
 @pytest.mark.parametrize("cfg_name", ["DALESPLConfig", "Vaihingen3DPLConfig"])

@@ -51,6 +51,25 @@ def main():
                     times[v].append(e0.elapsed_time(e1))
                     outs[v] = wf
             variant.value = 2
+            # ---- what a spatially sorted row layout would give: rows of points / features stored in the cell order of the
+            #      level's search grid, index matrix remapped (same values, same column order -> same sums)
+            order = ops._order_for(P)
+            if order is not None:
+                perm = order.long()
+                rank = torch.empty_like(perm)
+                rank[perm] = torch.arange(perm.numel(), device=dev)
+                rank_pad = torch.cat([rank, torch.tensor([perm.numel()], device=dev)])
+                Ps, xs = P[perm].contiguous(), x[perm].contiguous()
+                inds_s = rank_pad[inds[perm]].contiguous()
+                ts = []
+                for rd in range(rounds):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    wfs, _ = ops.kpconv_gather(xs, Ps, Ps, inds_s, kps, extent)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                print("      sorted layout: mfma %.4f ms; equal to the unsorted result %s" % (np.median(ts), torch.equal(wfs, outs[2][perm])), flush=True)
             same = torch.equal(outs[1], outs[2])
             md = (outs[1].float() - outs[2].float()).abs().max().item()
             n, h = inds.shape

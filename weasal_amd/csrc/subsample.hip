@@ -492,19 +492,22 @@ struct DevBuf {
 // bucket counts of a default std::unordered_map as it grows: 13, 29, 59, 127, ...
 const std::vector<unsigned long long>& prime_sequence()
 {
-    static std::vector<unsigned long long> seq;
-    if (seq.empty()) {
+    // built once, thread safe (the training thread and the prefetch thread may make their first call together):
+    // initialisation of a function-local static is serialised by the language
+    static const std::vector<unsigned long long> seq = [] {
+        std::vector<unsigned long long> v;
         std::__detail::_Prime_rehash_policy pol;   // max_load_factor 1.0, like the reference's map
         size_t bkt = 1, n_elt = 0;
-        while (seq.size() < 40) {
+        while (v.size() < 40) {
             const auto r = pol._M_need_rehash(bkt, n_elt, 1);
             if (!r.first) break;                   // cannot happen for n_elt == bkt
             bkt = r.second;
-            seq.push_back((unsigned long long)bkt);
+            v.push_back((unsigned long long)bkt);
             n_elt = bkt;                           // next growth when the size reaches the bucket count
             if (bkt > (1ull << 33)) break;
         }
-    }
+        return v;
+    }();
     return seq;
 }
 

@@ -169,25 +169,16 @@ class _KPBlockFn(torch.autograd.Function):
         d.out, d.dout = out.data_ptr(), dout.data_ptr()
         dfeat = torch.empty_like(feat) if need[0] else None
         d.dfeat = _p(dfeat)
-        # parameter gradients in one flat buffer
-        shapes = [None if w1 is None else w1.shape, None if b1 is None else b1.shape, wk.shape, None if bk is None else bk.shape,
-                  None if w2 is None else w2.shape, None if b2 is None else b2.shape, None if wsc is None else wsc.shape]
-        goffs, tot = [], 0
-        for s in shapes:
-            goffs.append(tot)
-            tot += _al(s.numel()) if s is not None else 0
-        flat = torch.empty(max(tot, 64), dtype=torch.float32, device=dev)
-        fb = flat.data_ptr()
-        ptrs = [fb + 4 * o if s is not None else None for o, s in zip(goffs, shapes)]
-        d.dw1, d.db1, d.dwk, d.dbk, d.dw2, d.db2, d.dws = ptrs
+        # parameter gradients: one tensor each (autograd adopts an unshared, contiguous gradient as .grad without a copy)
+        grads = [None if p is None else torch.empty_like(p) for p in (w1, b1, wk, bk, w2, b2, wsc)]
+        d.dw1, d.db1, d.dwk, d.dbk, d.dw2, d.db2, d.dws = [_p(t) for t in grads]
         nbytes = lib.ws_kpblock_bwd_scratch_bytes(C.byref(d))
         if nbytes < 0:
             check(1)
         scratch = _scratch(nbytes, dev)
         check(lib.ws_kpblock_bwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
-        grads = [flat[o:o + s.numel()].view(s) if s is not None else None for o, s in zip(goffs, shapes)]
         dw1, db1, dwk, dbk, dw2, db2, dws = grads
-        dbs = db2 if bsc is not None else None          # the shortcut bias sees the same dz as b2
+        dbs = db2.clone() if (bsc is not None and db2 is not None) else None          # the shortcut bias sees the same dz as b2
         return dfeat, dw1, db1, dwk, dbk, dw2, db2, dws, dbs, None
 
 
@@ -215,9 +206,15 @@ def _geometry(conv, q_pts, s_pts, inds, strided):
     return g
 
 
+# below this many rows a layer is launch-bound and its dense products are too short for the tall-skinny MFMA kernels
+# (split-K + epilogue + reduction launches): measured 0.6 ms per DALES step slower than the operator path, which hands
+# those products to the library GEMM
+MIN_ROWS = int(os.environ.get("WEASAL_FUSED_MIN_ROWS", "4096"))
+
+
 def kpblock_eligible(block, x):
     conv = block.KPConv
-    if not _conv_ok(conv, x):
+    if not _conv_ok(conv, x) or x.shape[0] < MIN_ROWS:
         return False
     dims = [conv.out_channels]
     if hasattr(block, "unary2"):
@@ -313,7 +310,7 @@ class _UpUnaryFn(torch.autograd.Function):
 def upunary_eligible(x, skip, unary):
     return (FUSED_BLOCKS and x.is_cuda and x.dtype == torch.float32 and skip.dtype == torch.float32
             and ops.kpconv_gather is _KPCONV_GATHER and x.shape[1] % 32 == 0 and skip.shape[1] % 32 == 0
-            and unary.out_dim % 32 == 0 and x.shape[0] > 0 and skip.shape[0] > 0)
+            and unary.out_dim % 32 == 0 and x.shape[0] > 0 and skip.shape[0] >= MIN_ROWS)
 
 
 def upunary(x, skip, unary, ups):

@@ -658,7 +658,22 @@ class _Workspaces:
         return self.sub[key]
 
 
+    def release_thread(self, device=None):
+        """destroy the calling thread's workspaces (a prefetch thread calls this when it ends: thread identifiers are
+        recycled, and a later thread must not inherit scratch that is still bound to another stream's work)"""
+        import threading
+        ident = threading.get_ident()
+        lib = _lib.lib()
+        for table, destroy in ((self.nb, lib.ws_neighbors_ws_destroy), (self.sub, lib.ws_subsample_ws_destroy)):
+            for key in [k for k in table if k[1] == ident and (device is None or k[0] == (torch.device(device).index or 0))]:
+                destroy(table.pop(key))
+
+
 _ws = _Workspaces()
+
+
+def release_thread_workspaces(device=None):
+    _ws.release_thread(device)
 
 
 class _DevView:

@@ -20,8 +20,11 @@ class PyramidPrefetcher:
     """Iterates PyramidBatch objects built ahead of time from `source`, an iterable of
     (points, features, labels, lengths) with device tensors and host lengths."""
 
-    def __init__(self, config, source, neighborhood_limits=(), depth=2, random_grid_orient=True, device=None):
+    def __init__(self, config, source, neighborhood_limits=(), depth=2, random_grid_orient=True, device=None, seed=None):
+        """seed: the background thread draws the grid orientations from its own numpy RandomState(seed); None keeps the
+        global np.random stream (what the reference's workers use; then no other thread may draw from it meanwhile)"""
         self.config = config
+        self.rng = None if seed is None else __import__("numpy").random.RandomState(seed)
         self.limits = neighborhood_limits
         self.rgo = random_grid_orient
         self.source = iter(source)
@@ -41,7 +44,8 @@ class PyramidPrefetcher:
                     if self._stop:
                         break
                     points, features, labels, lengths = item
-                    batch = pyramid.build_batch(self.config, points, features, labels, lengths, self.limits, self.rgo)
+                    batch = pyramid.build_batch(self.config, points, features, labels, lengths, self.limits, self.rgo,
+                                                rng=self.rng)
                     while not self._stop:
                         try:
                             self.queue.put(batch, timeout=0.1)
@@ -51,6 +55,12 @@ class PyramidPrefetcher:
         except BaseException as e:   # surfaced to the consumer
             self.error = e
         finally:
+            try:
+                self.stream.synchronize()               # nothing of this thread's scratch is in flight any more
+                from . import ops
+                ops.release_thread_workspaces(self.device)   # the thread owns its geometry workspaces: freed with it
+            except Exception:
+                pass
             while not self._stop:
                 try:
                     self.queue.put(None, timeout=0.1)

@@ -25,16 +25,18 @@ def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None)
     return ops.radius_neighbors(queries, supports, q_batches, s_batches, radius, limit=limit, dtype=torch.int64)
 
 
-def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_grid_orient=True):
-    """device form of datasets/common.py:77-182 (points only, the form the pyramid uses :521)"""
+def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_grid_orient=True, rng=None):
+    """device form of datasets/common.py:77-182 (points only, the form the pyramid uses :521).  `rng`: the
+    numpy RandomState the orientations are drawn from (default: the global np.random, like the reference)"""
     lens = np.asarray(batches_len, dtype=np.int32)
     B = len(lens)
     if not random_grid_orient:
         return ops.grid_subsample(points, lens, sampleDl, max_p=max_p)
-    theta = np.random.rand(B) * 2 * np.pi
-    phi = (np.random.rand(B) - 0.5) * np.pi
+    rand = np.random.rand if rng is None else rng.rand
+    theta = rand(B) * 2 * np.pi
+    phi = (rand(B) - 0.5) * np.pi
     u = np.vstack([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
-    alpha = np.random.rand(B) * 2 * np.pi
+    alpha = rand(B) * 2 * np.pi
     R = create_3D_rotations(u.T, alpha).astype(np.float32)
     rotated = ops.rotate_clouds_host(points, lens, R)
     s_points, s_len = ops.grid_subsample(rotated, lens, sampleDl, max_p=max_p)
@@ -43,7 +45,7 @@ def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_gr
 
 
 def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_lengths,
-                        neighborhood_limits=(), random_grid_orient=True, point_orders=None, search_grids=None):
+                        neighborhood_limits=(), random_grid_orient=True, point_orders=None, search_grids=None, rng=None):
     """-> flat list  points[L] + neighbors[L] + pools[L] + upsamples[L] + lengths[L] + [features, labels]
     (datasets/common.py:574-575), all device tensors (lengths int32, indices int64).
 
@@ -102,7 +104,7 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
         if 'pool' in block or 'strided' in block:
             dl = 2 * r_normal / config.conv_radius
             pool_p, pool_b = batch_grid_subsampling(stacked_points, lens, sampleDl=dl,
-                                                    random_grid_orient=random_grid_orient)
+                                                    random_grid_orient=random_grid_orient, rng=rng)
             r = r_normal * config.deform_radius / config.conv_radius if 'deformable' in block else r_normal
             pool_i = search(pool_p, stacked_points, pool_b, lens, r, layer)
             if deferred is not None:
@@ -236,10 +238,10 @@ class PyramidBatch:
 
 
 def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True,
-                with_tables=True):
+                with_tables=True, rng=None):
     orders, grids = [], []
     li = segmentation_inputs(config, points, features, labels, lengths, neighborhood_limits, random_grid_orient,
-                             point_orders=orders, search_grids=grids if points.is_cuda else None)
+                             point_orders=orders, search_grids=grids if points.is_cuda else None, rng=rng)
     batch = PyramidBatch(li, orders)
     batch.search_grids = grids
     if with_tables and points.is_cuda:

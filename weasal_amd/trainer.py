@@ -27,7 +27,9 @@ def train_step(net, optimizer, batch, config, grad_sync=None, epoch=None):
     """-> (loss tensor, logits).  grad_sync: optional callable(net) run between backward and clip
     (weasal_amd.dp.GradSync: one flat RCCL all-reduce).  epoch: when given, the supervised contrastive
     loss joins from `config.contrast_start` on (trainer_PseudoLabel.py:204-208)."""
-    optimizer.zero_grad(set_to_none=False)
+    # single process: gradients are dropped and re-assigned (autograd adopts the tensor the backward produced: no zero-fill
+    # and no accumulate-add kernel per parameter); data parallel: they stay the views of GradSync's flat buffer
+    optimizer.zero_grad(set_to_none=grad_sync is None)
     outputs = net(batch, config)
     loss = net.loss(outputs, batch.labels)
     if epoch is not None and epoch >= getattr(config, 'contrast_start', 1 << 30):
@@ -67,12 +69,32 @@ class InFlightLimiter:
     def __init__(self, depth=3):
         self.depth = max(1, int(depth))
         self.events = []
+        self._pinned = []
+        self._slot = -1
 
-    def tick(self):
+    def tick(self, batch=None):
+        """batch: the PyramidBatch this step trained on.  Its table-free backward launches (K4G) write a capacity flag
+        (`SearchGrid.overflow`, set if a support ever had more incoming pairs than the slab holds -- impossible while the
+        search reported rows <= 128, so a set flag means a stale or mutated grid); the flags travel to the host with an
+        asynchronous copy here and are checked `depth` steps later, when their event has completed anyway: never silent,
+        never a synchronisation on the step."""
         if not torch.cuda.is_available():
             return
+        flags = None
+        grids = getattr(batch, "search_grids", None) if batch is not None else None
+        if grids:
+            dev = torch.cat([g.overflow for _, g in grids])
+            if len(self._pinned) <= self.depth + 1:              # a small ring of pinned landing buffers, allocated once
+                self._pinned.append(torch.zeros(64, dtype=dev.dtype, pin_memory=True))
+            self._slot = (self._slot + 1) % len(self._pinned)
+            flags = self._pinned[self._slot][:dev.shape[0]]
+            flags.copy_(dev, non_blocking=True)
         e = torch.cuda.Event()
         e.record()
-        self.events.append(e)
+        self.events.append((e, flags))
         if len(self.events) > self.depth:
-            self.events.pop(0).synchronize()
+            ev, fl = self.events.pop(0)
+            ev.synchronize()
+            if fl is not None and int(fl.max()) != 0:
+                raise RuntimeError("KPConv backward through the search grid overflowed its pair slab (%d incoming pairs): the "
+                                   "grid does not belong to the index matrix it was used with" % int(fl.max()))
