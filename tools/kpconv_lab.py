@@ -70,6 +70,23 @@ def main():
                     torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1))
                 print("      sorted layout: mfma %.4f ms; equal to the unsorted result %s" % (np.median(ts), torch.equal(wfs, outs[2][perm])), flush=True)
+            if name == "enc1" and dt == torch.float32:
+                # ablations of the matrix-core form (diagnostics): which part of the memory traffic sets the time
+                abl = C.c_int.in_dll(lib, "ws_kpconv_ablate")
+                for mask, what in ((0, "full"), (1, "no wf store"), (2, "rows all = row 0"), (4, "xyz from 64 fixed points"),
+                                   (8, "no index load"), (3, "no store + rows 0"), (7, "no store, rows 0, xyz fixed"),
+                                   (15, "everything ablated"), (6, "rows 0 + xyz fixed"), (12, "xyz fixed + no idx")):
+                    abl.value = mask
+                    ts = []
+                    for rd in range(rounds):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        ops.kpconv_gather(x, P, P, inds, kps, extent)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                    print("      ablate %2d (%-28s): %.4f ms" % (mask, what, np.median(ts)), flush=True)
+                abl.value = 0
             same = torch.equal(outs[1], outs[2])
             md = (outs[1].float() - outs[2].float()).abs().max().item()
             n, h = inds.shape

@@ -22,6 +22,8 @@ struct GeomParams {
     int influence;
     int aggregation;
     int deformable;   // 1: apply the in-range filter of blocks.py:301-325
+    int ablate;       // diagnostics only (tools/kpconv_lab.py): 1 = no wf store, 2 = every row gather reads row 0,
+                      // 4 = coordinates of point `lane` instead of the neighbour's, 8 = no index load
 };
 
 // Influence of the K kernel points on one neighbour offset n = s - q.  kp is wave-uniform.
@@ -572,11 +574,13 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     auto item_q = [&](int64_t it) -> int64_t { return it < iend ? (order ? (int64_t)order[it] : it) : -1; };
     auto load_idx = [&](int64_t q, int col) -> int {
         if (q < 0 || col >= h) return -1;
+        if (g.ablate & 8) return (int)((q + 37 * col) % ns);
         const int64_t v = inds[q * h + col];
         return (v >= 0 && v < ns) ? (int)v : -1;
     };
     auto load_pt = [&](int idx, float& px, float& py, float& pz) {
         px = py = pz = WS_SHADOW;
+        if (g.ablate & 4) idx = idx >= 0 ? lane : idx;
         if (idx >= 0) { px = s_pts[3 * (int64_t)idx]; py = s_pts[3 * (int64_t)idx + 1]; pz = s_pts[3 * (int64_t)idx + 2]; }
     };
     // software pipeline over the items of this wave: indices two items ahead, coordinates one item ahead
@@ -617,16 +621,28 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                 const int steps = (cols + 3) >> 2;
                 float wb[2][GS];
                 float xb[2][GS][NT];
+                // three separate passes per group so that nothing waits between the independent accesses: all LDS
+                // broadcasts, then all row loads (addresses from the broadcasts), then the weights (VALU under the loads);
+                // selects instead of branches throughout (an exec-mask branch per step serialises the LDS round trips)
                 auto load_group = [&](int gi, int slot) {
+                    float4 nv[GS];
+#pragma unroll
+                    for (int u = 0; u < GS; ++u) nv[u] = nb[min(4 * (gi * GS + u) + kk, 63)];
 #pragma unroll
                     for (int u = 0; u < GS; ++u) {
                         const int s = gi * GS + u;
-                        const float4 n = nb[min(4 * s + kk, 63)];
-                        const int nidx = __float_as_int(n.w);     // >= 0 real, -2 shadow column, -1 past the row
+                        const int nidx = __float_as_int(nv[u].w);     // >= 0 real, -2 shadow column, -1 past the row
                         const bool live = nidx >= 0 && s < steps;
-                        const unsigned row = live ? (unsigned)nidx : 0u;
+                        const unsigned row = (live && !(g.ablate & 2)) ? (unsigned)nidx : 0u;
                         const T* src = x + (size_t)(row * (unsigned)ci) + (chok ? ch : 0);
                         RowLoad<NT, T>::ld(src, xb[slot][u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < GS; ++u) {
+                        const int s = gi * GS + u;
+                        const float4 n = nv[u];
+                        const int nidx = __float_as_int(n.w);
+                        const bool live = nidx >= 0 && s < steps;
                         // influence of this lane's kernel point on that neighbour
                         const float dx = n.x - kx, dy = n.y - ky, dz = n.z - kz;
                         const float d2 = (dx * dx + dy * dy) + dz * dz;
@@ -643,21 +659,19 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                                 for (int o = 1; o < 16; o <<= 1) {
                                     const float od = __shfl_xor(bd, o, 64);
                                     const int oi = __shfl_xor(bi, o, 64);
-                                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                                    const bool take = od < bd || (od == bd && oi < bi);
+                                    bd = take ? od : bd;
+                                    bi = take ? oi : bi;
                                 }
-                                if (bi != i) w = 0.0f;
+                                w = bi != i ? 0.0f : w;
                             }
                             if (DEF) {
                                 const unsigned long long m = __ballot(haskp && d2 < e2);
-                                if ((((unsigned)(m >> (16 * kk))) & 0xffffu) == 0u) w = 0.0f;     // no kernel point in range (blocks.py:301-325)
-                                if (nidx != -1 && s < steps && haskp) mind = fminf(mind, d2);
+                                w = ((((unsigned)(m >> (16 * kk))) & 0xffffu) == 0u) ? 0.0f : w;     // no kernel point in range (blocks.py:301-325)
+                                mind = (nidx != -1 && s < steps && haskp) ? fminf(mind, d2) : mind;
                             }
                         }
                         wb[slot][u] = (live && haskp) ? w : 0.0f;
-                        if (!chok) {
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) xb[slot][u][t] = 0.0f;
-                        }
                     }
                 };
                 auto comp_group = [&](int slot) {
@@ -665,7 +679,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                     for (int u = 0; u < GS; ++u)
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[slot][u], xb[slot][u][t], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[slot][u], chok ? xb[slot][u][t] : 0.0f, acc[t], 0, 0, 0);
                 };
                 const int ngroups = (steps + GS - 1) / GS;
                 load_group(0, 0);
@@ -692,7 +706,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
 #pragma unroll
                             for (int t = 0; t < NT; ++t) v[t] *= md;
                         }
-                        RowLoad<NT, T>::st(wf + (q * K + k) * ci + ch, v);
+                        if (!(g.ablate & 1) || v[0] == 1.2345e30f) RowLoad<NT, T>::st(wf + (q * K + k) * ci + ch, v);
                     }
                 }
             }
@@ -1195,6 +1209,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
 // diagnostic switch (tools / A-B tests), not part of the drop-in surface
 extern "C" int ws_kpconv_variant;
 int ws_kpconv_variant = 2;
+extern "C" int ws_kpconv_ablate;          // diagnostics (GeomParams::ablate); 0 in every product path
+int ws_kpconv_ablate = 0;
 
 namespace {
 
@@ -1210,7 +1226,7 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
     if (rc) return rc;
     if (nq == 0) return WS_OK;
     WS_REQUIRE(inds && x && wf && (kernel_points || deformed_kp), "NULL argument");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(nq, 4);
     WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
@@ -1295,7 +1311,7 @@ int gather_bwd_x_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_
     WS_REQUIRE(t_offsets && t_pairs && dwf && dx && (kernel_points || deformed_kp), "NULL argument");
     WS_REQUIRE(nq * (int64_t)h < (1ll << 31), "nq*h exceeds int32");
     WS_REQUIRE(nq * (int64_t)k * ci < (1ll << 31), "nq*k*ci exceeds the 32-bit row offsets of the gather");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
@@ -1336,7 +1352,7 @@ int gather_bwd_geom_impl(const float* q_pts, int64_t nq, const float* s_pts, int
     if (rc) return rc;
     if (nq == 0) return WS_OK;
     WS_REQUIRE(inds && x && dwf && deformed_kp && d_deformed_kp, "NULL argument");
-    GeomParams g{extent, influence, aggregation, 1};
+    GeomParams g{extent, influence, aggregation, 1, 0};
     hipStream_t st = (hipStream_t)stream;
     kpconv_gather_bwd_geom_kernel<15, T><<<ws_grid(nq, 4), 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf,
                                                                           deformed_kp, modulations, d_min_d2, g,
@@ -1360,7 +1376,7 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
     WS_REQUIRE(grid_blob && key_last && dwf && dx && overflow && (kernel_points || deformed_kp), "NULL argument");
     WS_REQUIRE(nb >= 1 && cells >= 1, "bad grid nb=%d cells=%lld", nb, (long long)cells);
     WS_REQUIRE(ns * (int64_t)k * ci < (1ll << 31), "ns*k*ci exceeds the 32-bit row offsets of the gather");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate};
     hipStream_t st = (hipStream_t)stream;
     const char* base = (const char*)grid_blob;
     const CloudGrid* grids = (const CloudGrid*)base;
