@@ -453,6 +453,28 @@ int ws_timer_reset(void);
 int ws_timer_count(void);
 int ws_timer_read(int32_t i, int64_t* nq, int32_t* h, int32_t* ci, float* ms);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Forward-only callers of the hot path: the voting test loop and the sampler potentials.
+ * ws_vote_update: utils/tester_PseudoLabel.py:168-194 -- for every point i of a sphere (n rows of `logits` [n,c]):
+ *   probs[inds[i], :] = smooth * probs[inds[i], :] + (1 - smooth) * softmax(logits[i, :]); with radius_mask > 0 only the
+ *   points with |points[i]|^2 < radius_mask^2 take part (test_radius_ratio * in_radius).  inds are unique inside a sphere.
+ * ws_project_confusion: tester_PseudoLabel.py:283-307 + utils/metrics.py:35-110 -- preds[i] = argmax_k probs[proj[i], k]
+ *   (first maximum; proj NULL = identity), confusion[t, p] += 1 for t = labels[i] in [0, nc) (int64 [nc, nc], must be
+ *   zeroed by the caller; accumulated over calls).
+ * ws_potentials_update: datasets/DALES_PseudoLabel.py:335-350 -- potentials[i] += (1 - d2/r^2)^2 for the coarse points
+ *   within `radius` of h_center (host double[3]), float64 arithmetic of the KDTree-based reference; then the new minimum
+ *   (value, first index) into out_min / out_argmin (device).  scratch: ws_potentials_scratch_bytes(n).
+ * The nearest-neighbour projection indices themselves (DALES_PseudoLabel.py:888-892) are column 0 of the K1 radius search.
+ * ------------------------------------------------------------------------------------------ */
+int ws_vote_update(const float* logits, int64_t n, int32_t c, const float* points, float radius_mask, const int64_t* inds,
+                   float* probs, int64_t n_cloud, float smooth, void* stream);
+int ws_project_confusion(const float* probs, int32_t c, const int32_t* proj, int64_t m, const int32_t* labels, int32_t* preds,
+                         int32_t nc, int64_t* confusion, void* stream);
+int64_t ws_potentials_scratch_bytes(int64_t n);
+int ws_potentials_update(const float* pot_points, int64_t n, const double* h_center, double radius, double* potentials,
+                         double* out_min, int64_t* out_argmin, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,19 @@ def main():
                         ts.append(e0.elapsed_time(e1))
                     print("      ablate %2d (%-28s): %.4f ms" % (mask, what, np.median(ts)), flush=True)
                 abl.value = 0
+                gsv = C.c_int.in_dll(lib, "ws_kpconv_gs")
+                for gs in (1, 2, 4, 8):
+                    gsv.value = gs
+                    ts = []
+                    for rd in range(rounds):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        ops.kpconv_gather(x, P, P, inds, kps, extent)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                    print("      group size %d: %.4f ms" % (gs, np.median(ts)), flush=True)
+                gsv.value = 0
             same = torch.equal(outs[1], outs[2])
             md = (outs[1].float() - outs[2].float()).abs().max().item()
             n, h = inds.shape

@@ -71,6 +71,16 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LDS-only ordering inside one wave: the wavefront-scope release/acquire fences above make the compiler drain EVERY
+// outstanding vector-memory load (s_waitcnt vmcnt(0)), i.e. they expose the full latency of loads that were issued on
+// purpose ahead of their use.  A wave's own LDS writes and reads are ordered by the LDS queue; what is needed is that the
+// compiler keeps them in program order and that the wave's earlier LDS operations have completed.
+__device__ __forceinline__ void wave_lds_order()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pool + accumulate structure shared by K3 (forward) and K4 (backward w.r.t. x).
 //
@@ -488,6 +498,9 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
 // instructions of the pool form.  MODE / DEF as above (MODE 0 = rigid, linear, sum).
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifndef WS_K3_GS
+#define WS_K3_GS 4
+#endif
 
 template <int NT, typename T> struct RowLoad;
 template <int NT> struct RowLoad<NT, float> {
@@ -543,7 +556,7 @@ template <int NT> struct RowLoad<NT, bf16_t> {
 };
 
 // VECROW: ci is a multiple of NT and rows are aligned for NT-element accesses (else NT == 1 with per-lane masking)
-template <int NT, int MODE, bool DEF, bool VECROW, typename T>
+template <int NT, int MODE, bool DEF, bool VECROW, typename T, int GSV = 0>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci,
@@ -553,7 +566,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
 {
     constexpr int K = 15;
     constexpr int CB = 16 * NT;                                   // channels per block
-    constexpr int GS = NT <= 2 ? 8 : (NT == 4 ? 4 : (NT == 8 ? 2 : 1));   // steps whose loads are in flight together
+    // steps whose loads are in flight together (per buffer; two buffers): more = deeper memory pipelining per wave,
+    // fewer = fewer registers = more waves per SIMD.  The kernel is bound by instruction latency x occupancy (with every
+    // memory access ablated it still takes 0.53 of its 0.68 ms on the 400k x 59 x 32 layer), so registers win
+    constexpr int GS = GSV > 0 ? GSV : (NT <= 2 ? WS_K3_GS : (NT == 4 ? 2 : 1));
     static_assert(!(DEF && MODE == 0), "deformable layers use MODE 1");
     static_assert(VECROW || NT == 1, "masked rows use one channel per lane");
     __shared__ float4 nb_all[4][64];
@@ -583,19 +599,48 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
         if (g.ablate & 4) idx = idx >= 0 ? lane : idx;
         if (idx >= 0) { px = s_pts[3 * (int64_t)idx]; py = s_pts[3 * (int64_t)idx + 1]; pz = s_pts[3 * (int64_t)idx + 2]; }
     };
-    // software pipeline over the items of this wave: indices two items ahead, coordinates one item ahead
+    // software pipeline over the items of this wave: indices two items ahead, coordinates (neighbours and query) one item
+    // ahead.  The loads for the later items are issued AFTER this item's neighbourhood has been staged in LDS and right
+    // before its row loads, so that nothing between here and the first MFMA has to wait for them (vmcnt retires in order:
+    // they complete under the row loads), and the staging at the top of the next iteration finds them done.
+    auto load_q = [&](int64_t q, float& x_, float& y_, float& z_) {
+        const int64_t qq = q >= 0 ? q : 0;                        // unconditional (clamped): no control flow around the load
+        x_ = q_pts[3 * qq + 0]; y_ = q_pts[3 * qq + 1]; z_ = q_pts[3 * qq + 2];
+    };
+    // prefetch forms: the loaded values are NOT looked at here (a use would make the compiler wait for the load on the
+    // spot); the validity checks happen when the item is staged
+    auto load_idx_raw = [&](int64_t q) -> int64_t {
+        const int64_t qq = q >= 0 ? q : 0;
+        const int col = lane < h ? lane : 0;
+        if (g.ablate & 8) return (qq + 37 * col) % ns;
+        return inds[qq * h + col];
+    };
+    auto check_idx = [&](int64_t raw, int64_t q) -> int {
+        return (q >= 0 && lane < h && raw >= 0 && raw < ns) ? (int)raw : -1;
+    };
+    auto load_pt_raw = [&](int idx, float& px, float& py, float& pz) {
+        int ii = idx >= 0 ? idx : 0;
+        if (g.ablate & 4) ii = lane;
+        px = s_pts[3 * (int64_t)ii]; py = s_pts[3 * (int64_t)ii + 1]; pz = s_pts[3 * (int64_t)ii + 2];
+    };
     int64_t q0 = item_q(ibeg + wave), q1 = item_q(ibeg + wave + 4);
-    int idx0 = load_idx(q0, lane), idx1 = load_idx(q1, lane);
-    float p0x, p0y, p0z;
+    int idx0 = load_idx(q0, lane);
+    int64_t raw1 = load_idx_raw(q1);
+    float p0x, p0y, p0z, qx, qy, qz;
     load_pt(idx0, p0x, p0y, p0z);
+    load_q(q0, qx, qy, qz);
+    int idx1 = check_idx(raw1, q1);
 
     for (int64_t item = ibeg + wave; item < iend; item += 4) {
         const int64_t q = q0;
+        // the later items' loads go out first and unconditionally (a conditional issue makes their results phi values
+        // that the compiler must wait for at the join); nothing waits for them before this item's row loads do: the LDS
+        // ordering below only counts LDS operations (wave_lds_order), the staging reads registers filled an item ago
         const int64_t q2 = item_q(item + 8);
-        const int idx2 = load_idx(q2, lane);
-        float p1x, p1y, p1z;
-        load_pt(idx1, p1x, p1y, p1z);
-        const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
+        const int64_t raw2 = load_idx_raw(q2);
+        float p1x, p1y, p1z, q1x, q1y, q1z;
+        load_pt_raw(idx1, p1x, p1y, p1z);
+        load_q(q1, q1x, q1y, q1z);
         if (DEF && haskp) {
             const float* kp = deformed_kp + q * (3 * K) + 3 * i;
             kx = kp[0]; ky = kp[1]; kz = kp[2];
@@ -614,9 +659,9 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                     idx = load_idx(q, h0 + lane);
                     load_pt(idx, px, py, pz);
                 }
-                wave_lds_sync();                                  // the previous chunk's readers are done
+                wave_lds_order();                                 // the previous chunk's readers are done
                 nb[lane] = make_float4(px - qx, py - qy, pz - qz, __int_as_float((h0 + lane < h) ? (idx >= 0 ? idx : -2) : -1));
-                wave_lds_sync();
+                wave_lds_order();
                 const int cols = min(64, h - h0);
                 const int steps = (cols + 3) >> 2;
                 float wb[2][GS];
@@ -701,7 +746,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                         float v[NT];
 #pragma unroll
                         for (int t = 0; t < NT; ++t) v[t] = acc[t][r];
-                        if (modulations) {
+                        if (MODE != 0 && modulations) {
                             const float md = modulations[q * K + k];
 #pragma unroll
                             for (int t = 0; t < NT; ++t) v[t] *= md;
@@ -716,9 +761,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
             mind = fminf(mind, __shfl_xor(mind, 32, 64));
             if (kk == 0 && haskp) min_d2[q * K + i] = mind;
         }
+        // rotate; the checks / selects on the prefetched values happen here, one item after their loads were issued
+        p0x = idx1 >= 0 ? p1x : WS_SHADOW; p0y = idx1 >= 0 ? p1y : WS_SHADOW; p0z = idx1 >= 0 ? p1z : WS_SHADOW;
+        idx0 = idx1;
+        idx1 = check_idx(raw2, q2);
         q0 = q1; q1 = q2;
-        idx0 = idx1; idx1 = idx2;
-        p0x = p1x; p0y = p1y; p0z = p1z;
+        qx = q1x; qy = q1y; qz = q1z;
     }
 }
 
@@ -1211,6 +1259,8 @@ extern "C" int ws_kpconv_variant;
 int ws_kpconv_variant = 2;
 extern "C" int ws_kpconv_ablate;          // diagnostics (GeomParams::ablate); 0 in every product path
 int ws_kpconv_ablate = 0;
+extern "C" int ws_kpconv_gs;              // diagnostics: > 0 forces the group size of the Ci = 32 matrix-core kernel
+int ws_kpconv_gs = 0;
 
 namespace {
 
@@ -1243,6 +1293,18 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
 #define WS_FWDM2(NTV, MODEV, DEFV)                                                                                  \
     kpconv_gather_fwd_mfma_kernel<NTV, MODEV, DEFV, true, T><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, \
                                                                                    kernel_points, deformed_kp, modulations, g, wf, min_d2, order)
+        if (F32 && nt == 2 && fastm && ws_kpconv_gs > 0) {      // diagnostics: group-size sweep on the dominant shape
+            if constexpr (F32) {
+#define WS_FWDG(GSX) kpconv_gather_fwd_mfma_kernel<2, 0, false, true, T, GSX><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points, deformed_kp, modulations, g, wf, min_d2, order)
+                if (ws_kpconv_gs == 1) WS_FWDG(1);
+                else if (ws_kpconv_gs == 2) WS_FWDG(2);
+                else if (ws_kpconv_gs == 4) WS_FWDG(4);
+                else WS_FWDG(8);
+#undef WS_FWDG
+            }
+            WS_LAUNCH_CHECK();
+            return WS_OK;
+        }
 #define WS_FWDM(NTV)                                    \
     do {                                                \
         if (deformed_kp) WS_FWDM2(NTV, 1, true);        \
