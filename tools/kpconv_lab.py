@@ -75,7 +75,8 @@ def main():
                 abl = C.c_int.in_dll(lib, "ws_kpconv_ablate")
                 for mask, what in ((0, "full"), (1, "no wf store"), (2, "rows all = row 0"), (4, "xyz from 64 fixed points"),
                                    (8, "no index load"), (3, "no store + rows 0"), (7, "no store, rows 0, xyz fixed"),
-                                   (15, "everything ablated"), (6, "rows 0 + xyz fixed"), (12, "xyz fixed + no idx")):
+                                   (15, "all memory ablated"), (15 + 16, "+ no MFMA"), (15 + 32, "+ no influence math"),
+                                   (15 + 64, "+ no row loads"), (15 + 128, "+ no LDS reads"), (15 + 16 + 32 + 64 + 128, "+ all of these")):
                     abl.value = mask
                     ts = []
                     for rd in range(rounds):

@@ -587,60 +587,62 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     float kx = 0.f, ky = 0.f, kz = 0.f;
     if (!DEF && haskp) { kx = kernel_points[3 * i]; ky = kernel_points[3 * i + 1]; kz = kernel_points[3 * i + 2]; }
 
-    auto item_q = [&](int64_t it) -> int64_t { return it < iend ? (order ? (int64_t)order[it] : it) : -1; };
-    auto load_idx = [&](int64_t q, int col) -> int {
-        if (q < 0 || col >= h) return -1;
-        if (g.ablate & 8) return (int)((q + 37 * col) % ns);
-        const int64_t v = inds[q * h + col];
-        return (v >= 0 && v < ns) ? (int)v : -1;
+    // ---- software pipeline over the items of this wave.  Everything an item needs before its row loads -- its query index
+    // (order[]), its index row, the neighbours' coordinates, its own coordinates -- is a chain of dependent memory
+    // accesses of ~1 us each; executed at the item they would leave the wave idle for several microseconds per query (the
+    // first forms of this kernel spent 0.47 of 0.68 ms with EVERY memory access and all arithmetic ablated).  So the chain
+    // is spread over three items: at the top of item t the wave issues  order[t+3],  inds / q_pts of item t+2,  the
+    // neighbour coordinates of item t+1,  and looks at none of the results before the next iteration.  All of them are
+    // VECTOR loads, also the lane-uniform ones (order, q_pts: the address carries an opaque zero VGPR): scalar loads share
+    // the lgkm counter with LDS and return out of order, so the LDS ordering below would wait for them on the spot.
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    const int64_t it0 = ibeg + wave;
+    if (it0 >= iend) return;
+    auto item_v = [&](int64_t it) -> int {                        // query of item `it`, in a VGPR (clamped past the end)
+        const int64_t itc = it < iend ? it : iend - 1;
+        return order ? order[itc + vz] : (int)itc + vz;
     };
-    auto load_pt = [&](int idx, float& px, float& py, float& pz) {
-        px = py = pz = WS_SHADOW;
-        if (g.ablate & 4) idx = idx >= 0 ? lane : idx;
-        if (idx >= 0) { px = s_pts[3 * (int64_t)idx]; py = s_pts[3 * (int64_t)idx + 1]; pz = s_pts[3 * (int64_t)idx + 2]; }
+    const int col0 = lane < h ? lane : 0;
+    auto raw_idx = [&](int qv) -> int64_t {
+        if (g.ablate & 8) return ((int64_t)qv + 37 * col0) % ns;
+        return inds[(int64_t)qv * h + col0];
     };
-    // software pipeline over the items of this wave: indices two items ahead, coordinates (neighbours and query) one item
-    // ahead.  The loads for the later items are issued AFTER this item's neighbourhood has been staged in LDS and right
-    // before its row loads, so that nothing between here and the first MFMA has to wait for them (vmcnt retires in order:
-    // they complete under the row loads), and the staging at the top of the next iteration finds them done.
-    auto load_q = [&](int64_t q, float& x_, float& y_, float& z_) {
-        const int64_t qq = q >= 0 ? q : 0;                        // unconditional (clamped): no control flow around the load
-        x_ = q_pts[3 * qq + 0]; y_ = q_pts[3 * qq + 1]; z_ = q_pts[3 * qq + 2];
-    };
-    // prefetch forms: the loaded values are NOT looked at here (a use would make the compiler wait for the load on the
-    // spot); the validity checks happen when the item is staged
-    auto load_idx_raw = [&](int64_t q) -> int64_t {
-        const int64_t qq = q >= 0 ? q : 0;
-        const int col = lane < h ? lane : 0;
-        if (g.ablate & 8) return (qq + 37 * col) % ns;
-        return inds[qq * h + col];
-    };
-    auto check_idx = [&](int64_t raw, int64_t q) -> int {
-        return (q >= 0 && lane < h && raw >= 0 && raw < ns) ? (int)raw : -1;
-    };
-    auto load_pt_raw = [&](int idx, float& px, float& py, float& pz) {
+    auto chk = [&](int64_t raw) -> int { return (lane < h && raw >= 0 && raw < ns) ? (int)raw : -1; };
+    auto pt_raw = [&](int idx, float& px, float& py, float& pz) {
         int ii = idx >= 0 ? idx : 0;
         if (g.ablate & 4) ii = lane;
         px = s_pts[3 * (int64_t)ii]; py = s_pts[3 * (int64_t)ii + 1]; pz = s_pts[3 * (int64_t)ii + 2];
     };
-    int64_t q0 = item_q(ibeg + wave), q1 = item_q(ibeg + wave + 4);
-    int idx0 = load_idx(q0, lane);
-    int64_t raw1 = load_idx_raw(q1);
-    float p0x, p0y, p0z, qx, qy, qz;
-    load_pt(idx0, p0x, p0y, p0z);
-    load_q(q0, qx, qy, qz);
-    int idx1 = check_idx(raw1, q1);
+    auto q_xyz = [&](int qv, float& x_, float& y_, float& z_) {
+        x_ = q_pts[3 * (int64_t)qv + 0]; y_ = q_pts[3 * (int64_t)qv + 1]; z_ = q_pts[3 * (int64_t)qv + 2];
+    };
+    auto load_idx = [&](int qv, int col) -> int {                  // (further 64-column chunks of wide rows: at use)
+        if (col >= h) return -1;
+        const int64_t v = inds[(int64_t)qv * h + col];
+        return (v >= 0 && v < ns) ? (int)v : -1;
+    };
+    auto load_pt = [&](int idx, float& px, float& py, float& pz) {
+        px = py = pz = WS_SHADOW;
+        if (idx >= 0) { px = s_pts[3 * (int64_t)idx]; py = s_pts[3 * (int64_t)idx + 1]; pz = s_pts[3 * (int64_t)idx + 2]; }
+    };
+    int qv0 = item_v(it0), qv1 = item_v(it0 + 4), qv2 = item_v(it0 + 8);
+    int64_t raw1 = raw_idx(qv1);
+    int idx0 = chk(raw_idx(qv0));
+    float p0x, p0y, p0z, qx, qy, qz, q1x, q1y, q1z;
+    pt_raw(idx0, p0x, p0y, p0z);
+    p0x = idx0 >= 0 ? p0x : WS_SHADOW; p0y = idx0 >= 0 ? p0y : WS_SHADOW; p0z = idx0 >= 0 ? p0z : WS_SHADOW;
+    q_xyz(qv0, qx, qy, qz);
+    q_xyz(qv1, q1x, q1y, q1z);
+    int idx1 = chk(raw1);
 
-    for (int64_t item = ibeg + wave; item < iend; item += 4) {
-        const int64_t q = q0;
-        // the later items' loads go out first and unconditionally (a conditional issue makes their results phi values
-        // that the compiler must wait for at the join); nothing waits for them before this item's row loads do: the LDS
-        // ordering below only counts LDS operations (wave_lds_order), the staging reads registers filled an item ago
-        const int64_t q2 = item_q(item + 8);
-        const int64_t raw2 = load_idx_raw(q2);
-        float p1x, p1y, p1z, q1x, q1y, q1z;
-        load_pt_raw(idx1, p1x, p1y, p1z);
-        load_q(q1, q1x, q1y, q1z);
+    for (int64_t item = it0; item < iend; item += 4) {
+        const int64_t q = qv0;                                    // (a VGPR value, the same in every lane)
+        const int qv3 = item_v(item + 12);
+        const int64_t raw2 = raw_idx(qv2);
+        float q2x, q2y, q2z, p1x, p1y, p1z;
+        q_xyz(qv2, q2x, q2y, q2z);
+        pt_raw(idx1, p1x, p1y, p1z);
         if (DEF && haskp) {
             const float* kp = deformed_kp + q * (3 * K) + 3 * i;
             kx = kp[0]; ky = kp[1]; kz = kp[2];
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                 int idx = idx0;
                 float px = p0x, py = p0y, pz = p0z;
                 if (h0 > 0) {
-                    idx = load_idx(q, h0 + lane);
+                    idx = load_idx(qv0, h0 + lane);
                     load_pt(idx, px, py, pz);
                 }
                 wave_lds_order();                                 // the previous chunk's readers are done
@@ -672,7 +674,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                 auto load_group = [&](int gi, int slot) {
                     float4 nv[GS];
 #pragma unroll
-                    for (int u = 0; u < GS; ++u) nv[u] = nb[min(4 * (gi * GS + u) + kk, 63)];
+                    for (int u = 0; u < GS; ++u)
+                        nv[u] = nb[min(4 * (gi * GS + u) + kk, 63)];
 #pragma unroll
                     for (int u = 0; u < GS; ++u) {
                         const int s = gi * GS + u;
@@ -764,9 +767,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
         // rotate; the checks / selects on the prefetched values happen here, one item after their loads were issued
         p0x = idx1 >= 0 ? p1x : WS_SHADOW; p0y = idx1 >= 0 ? p1y : WS_SHADOW; p0z = idx1 >= 0 ? p1z : WS_SHADOW;
         idx0 = idx1;
-        idx1 = check_idx(raw2, q2);
-        q0 = q1; q1 = q2;
+        idx1 = chk(raw2);
+        qv0 = qv1; qv1 = qv2; qv2 = qv3;
         qx = q1x; qy = q1y; qz = q1z;
+        q1x = q2x; q1y = q2y; q1z = q2z;
     }
 }
 
