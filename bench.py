@@ -314,10 +314,12 @@ def main():
                     traffic = tj.get("kpconv_gather_fwd_bytes_per_launch", {}).get("%s:%d:%d" % (args.workload, h, ci))
                 except Exception:
                     traffic = None
-            G = max(1, ci // 4)
+            nt = 1 if ci <= 16 else (2 if ci <= 32 else (4 if ci <= 64 else (8 if ci <= 128 else 16)))
+            deform = "deform" in args.workload
             res["roofline"] = {"bound": "hbm",
-                               "kernel": "kpconv_gather_fwd_kernel<15,%d,0,false,true,4,%s> (N=%d queries, H=%d, Ci=%d)"
-                                         % (min(G, 16), "bf16" if bf16 else "float", nq, h, ci),
+                               "kernel": "kpconv_gather_fwd_mfma_kernel<%d,%d,false,true,%s> (the rigid gather of the largest layer: "
+                                         "N=%d queries, H=%d, Ci=%d)" % (nt, 0, "bf16" if bf16 else "float", nq, h, ci)
+                                         + ("; this workload's deformable gathers run the <.,1,true,...> instantiation" if deform else ""),
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "achieved_is": "SURVEY 8d logical-gather bytes B_fwd / launch time (every neighbour reference "
