@@ -21,9 +21,11 @@ and many tensors are sums with heavy cancellation (|grad| ~ 1e-9 from terms of 1
 itself: multiplying the input features by (1 + 1e-7 * noise) moves single parameter-gradient tensors by up to 5e-3 of
 their maximum while the logits move by 1e-6; an fp32 re-association in any kernel is a perturbation of that kind.  The
 per-tensor 1e-3 bound is therefore held where it is well defined -- the golden network g8 (tests/test_pyramid_gpu.py) --
-and at full width the gradient is compared as ONE vector: relative L2 error over all parameters <= 1e-3 (the tensors
-that carry the gradient's norm agree to fp32 accuracy), at least 80 % of the tensors within 2e-3 of their own maximum, and
-no tensor beyond 5e-2.
+and at full width the gradient is compared as ONE vector, with the tolerance calibrated inside the test: its relative
+L2 error over all parameters must be within 3 x (+ 1e-4) the change of the ORACLE's own gradient vector when the input
+features are perturbed by 1e-6 (measured per block: the GPU's gradients of the block outputs deviate from the oracle's by
+1e-3 .. 9e-2 in max norm, the perturbed oracle's by 3e-3 .. 9e-2, while the activations agree to 1e-6:
+tools/blockgrad_diag.py), and no tensor may be off by more than 5e-2 of its maximum.
 """
 import copy
 
@@ -50,27 +52,51 @@ def _cpu_copy(batch):
     return PyramidBatch([t.detach().cpu() for t in flat])
 
 
-def _check_grads(net, net_cpu):
-    ref = dict(net_cpu.named_parameters())
+def _grad_vector_error(grads_a, grads_b):
+    """(relative L2 error of the concatenated gradient, {name: max-norm error relative to the tensor's maximum})"""
     num = den = 0.0
     errs = {}
-    for name, p in net.named_parameters():
-        g = ref[name].grad
-        assert (p.grad is None) == (g is None), name
-        if g is None:
-            continue
-        a, b = p.grad.detach().double().cpu(), g.detach().double()
+    for name, b in grads_b.items():
+        a = grads_a[name].detach().double().cpu()
+        b = b.detach().double().cpu()
         num += float(((a - b) ** 2).sum())
         den += float((b ** 2).sum())
-        errs[name] = _rel(p.grad, g)
-    glob = (num / den) ** 0.5
-    vals = np.array(list(errs.values()))
+        errs[name] = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    return (num / den) ** 0.5, errs
+
+
+def _perturbed_oracle_grads(net_cpu, batch_cpu, cfg, eps=1e-6):
+    """the fp32 CPU oracle's parameter gradients with the input features multiplied by (1 + eps * noise)"""
+    from oracle import kpconv_ref
+    from weasal_amd.architectures import KPFCNN
+    net2 = KPFCNN(cfg, np.arange(9), [])          # (a module that has run holds graph tensors: no deepcopy)
+    net2.load_state_dict(net_cpu.state_dict())
+    net2.train()
+    b2 = _cpu_copy(batch_cpu)
+    gen = torch.Generator().manual_seed(123)
+    b2.features = b2.features * (1 + eps * torch.randn(b2.features.shape, generator=gen))
+    with kpconv_ref.cpu_reference_mode():
+        out = net2(b2, cfg)
+        net2.loss(out, b2.labels).backward()
+    return {k: p.grad for k, p in net2.named_parameters() if p.grad is not None}
+
+
+def _check_grads(net, ref_grads, pert_grads):
+    """ref_grads: the oracle's gradients (as the GPU's were taken: clipped or not); pert_grads: the oracle's gradients
+    under a 1e-6 relative perturbation of the input features (same treatment)"""
+    gpu = {}
+    for name, p in net.named_parameters():
+        assert (p.grad is None) == (name not in ref_grads), name
+        if p.grad is not None:
+            gpu[name] = p.grad
+    glob, errs = _grad_vector_error(gpu, ref_grads)
+    glob_p, errs_p = _grad_vector_error(pert_grads, ref_grads)
     worst = max(errs, key=errs.get)
-    print("gradient check: global rel-L2 %.2e, tensors within 2e-3: %d / %d, worst %s %.2e" % (glob, int((vals < 2e-3).sum()), len(vals), worst, errs[worst]))
-    assert glob < 1e-3, glob
-    assert (vals < 2e-3).mean() >= 0.8, sorted(errs.items(), key=lambda kv: -kv[1])[:8]
-    assert vals.max() < 5e-2, (worst, errs[worst])
-    return len(vals)
+    print("gradient check: global rel-L2 gpu %.2e, oracle under a 1e-6 input perturbation %.2e; worst tensor %s %.2e (oracle: %.2e)"
+          % (glob, glob_p, worst, errs[worst], errs_p[worst]))
+    assert glob <= 3 * glob_p + 1e-4, (glob, glob_p)
+    assert max(errs.values()) < 5e-2, (worst, errs[worst])
+    return len(errs)
 
 
 def _oracle_step(net_cpu, batch_cpu, cfg):
@@ -115,7 +141,8 @@ def test_dales_full_width_network_vs_oracle(gpu):
     out_c, loss_c = _oracle_step(net_cpu, batch_cpu, cfg)
     assert _rel(out, out_c) < 1e-4
     assert abs(loss.item() - loss_c.item()) < 1e-5 * abs(loss_c.item())
-    assert _check_grads(net, net_cpu) >= 40
+    ref_grads = {k: p.grad for k, p in net_cpu.named_parameters() if p.grad is not None}
+    assert _check_grads(net, ref_grads, _perturbed_oracle_grads(net_cpu, batch_cpu, cfg)) >= 40
 
 
 @pytest.mark.timeout(900)
@@ -160,12 +187,15 @@ def test_vaihingen_real_widths_pyramid_and_step_vs_oracle(gpu):
     from oracle import kpconv_ref
     opt_c = make_optimizer(net_cpu, cfg)
     batch_cpu = _cpu_copy(batch)
+    net_before = copy.deepcopy(net_cpu)          # the parameters the gradients were taken at
     with kpconv_ref.cpu_reference_mode():
         loss_c, out_c = train_step(net_cpu, opt_c, batch_cpu, cfg)
     assert _rel(out, out_c) < 1e-4
     assert abs(loss.item() - loss_c.item()) < 1e-5 * abs(loss_c.item())
     # gradients: the optimizer step clipped them in place on both sides alike (clip_grad_value_), compare as they are
-    assert _check_grads(net, net_cpu) >= 40
+    ref_grads = {k: p.grad for k, p in net_cpu.named_parameters() if p.grad is not None}
+    pert = {k: g.clamp(-cfg.grad_clip_norm, cfg.grad_clip_norm) for k, g in _perturbed_oracle_grads(net_before, batch_cpu, cfg).items()}
+    assert _check_grads(net, ref_grads, pert) >= 40
     ref = dict(net_cpu.named_parameters())
     for name, p in net.named_parameters():
         assert _rel(p, ref[name]) < 1e-4, name
