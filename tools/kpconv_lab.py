@@ -18,6 +18,8 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.lib()
     variant = C.c_int.in_dll(lib, "ws_kpconv_variant")
+    if os.environ.get("WEASAL_K3_ABLATE"):          # counter runs of an ablated kernel (diagnostics)
+        C.c_int.in_dll(lib, "ws_kpconv_ablate").value = int(os.environ["WEASAL_K3_ABLATE"])
     wl = synthetic.WORKLOADS["dales"]
     cfg = wcfg.DALESPLConfig()
     pts, feats, labels, lens = synthetic.make_inputs(1, wl["spheres"], wl["points"], wl["radius"], cfg.in_features_dim)

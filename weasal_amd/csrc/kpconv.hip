@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
 
     float kx = 0.f, ky = 0.f, kz = 0.f;
     if (!DEF && haskp) { kx = kernel_points[3 * i]; ky = kernel_points[3 * i + 1]; kz = kernel_points[3 * i + 2]; }
+    if (MODE == 0 && !haskp) kx = ky = kz = 1.0e9f;               // the 16th "kernel point": far from everything, weight 0
 
     // ---- software pipeline over the items of this wave.  Everything an item needs before its row loads -- its query index
     // (order[]), its index row, the neighbours' coordinates, its own coordinates -- is a chain of dependent memory
@@ -662,6 +663,77 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                     load_pt(idx, px, py, pz);
                 }
                 wave_lds_order();                                 // the previous chunk's readers are done
+                if constexpr (MODE == 0) {
+                    // ---- rigid / linear / sum: the instruction-lean form.  This kernel is bound by vector-instruction issue
+                    // (SQ counters: the SIMDs issue ~88 % of the time, 435 VALU per query in the first form), so everything
+                    // that can be decided once per neighbour is decided by the lane that stages it, not by the 16 lanes that
+                    // consume it:  * a column that is not a real neighbour (shadow index, past the row) is staged as the
+                    // shadow point (1e6,1e6,1e6) with row offset 0 -- its linear influence is exactly 0, no mask per step;
+                    // * the row's element offset idx*ci is computed at staging;  * channel lanes past ci load row 0 and feed
+                    // output columns that are never stored, no select;  * two steps share every arithmetic instruction
+                    // (v_pk_* on float2): the staging layout puts (x_a,x_b,y_a,y_b) and (z_a,z_b,off_a,off_b) of the step
+                    // pair (a, b) of a row group side by side, one ds_read_b128 each.
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    float* nbf = reinterpret_cast<float*>(nb);       // [pair p = 0..7][kk = 0..3][8 floats]
+                    {
+                        const bool real = idx >= 0 && (h0 + lane < h);
+                        const float sx = real ? px - qx : WS_SHADOW, sy = real ? py - qy : WS_SHADOW, sz = real ? pz - qz : WS_SHADOW;
+                        const unsigned off = real && !(g.ablate & 2) ? (unsigned)idx * (unsigned)ci : 0u;
+                        const int sstep = lane >> 2, skk = lane & 3;  // this lane's neighbour is column 4 sstep + skk
+                        float* dst = nbf + (((sstep >> 1) * 4 + skk) * 8) + (sstep & 1);
+                        dst[0] = sx; dst[2] = sy; dst[4] = sz; dst[6] = __uint_as_float(off);
+                    }
+                    wave_lds_order();
+                    const int cols = min(64, h - h0);
+                    const int steps = (cols + 3) >> 2;
+                    const int npairs = (steps + 1) >> 1;
+                    constexpr int GP = GS >= 2 ? GS / 2 : 1;         // step pairs whose loads are in flight together
+                    const T* xlane = x + (chok ? ch : 0);
+                    f2 wb2[2][GP];
+                    float xb[2][2 * GP][NT];
+                    auto load_pairs = [&](int gi, int slot) {
+                        float4 va[GP], vb[GP];
+#pragma unroll
+                        for (int u = 0; u < GP; ++u) {
+                            const float4* src = reinterpret_cast<const float4*>(nbf + ((gi * GP + u) * 4 + kk) * 8);
+                            va[u] = src[0];
+                            vb[u] = src[1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < GP; ++u) {
+                            RowLoad<NT, T>::ld(xlane + __float_as_uint(vb[u].z), xb[slot][2 * u]);
+                            RowLoad<NT, T>::ld(xlane + __float_as_uint(vb[u].w), xb[slot][2 * u + 1]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < GP; ++u) {
+                            const f2 dx = f2{va[u].x, va[u].y} - kx, dy = f2{va[u].z, va[u].w} - ky, dz = f2{vb[u].x, vb[u].y} - kz;
+                            const f2 d2 = (dx * dx + dy * dy) + dz * dz;
+                            const f2 sd = f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+                            const f2 w = 1.0f - sd * inv_extent;
+                            wb2[slot][u] = f2{fmaxf(w.x, 0.0f), fmaxf(w.y, 0.0f)};
+                        }
+                    };
+                    auto comp_pairs = [&](int slot) {
+#pragma unroll
+                        for (int u = 0; u < GP; ++u) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb2[slot][u].x, xb[slot][2 * u][t], acc[t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb2[slot][u].y, xb[slot][2 * u + 1][t], acc[t], 0, 0, 0);
+                        }
+                    };
+                    const int ngroups = (npairs + GP - 1) / GP;
+                    load_pairs(0, 0);
+                    for (int gi = 0; gi < ngroups; gi += 2) {
+                        if (gi + 1 < ngroups) load_pairs(gi + 1, 1);
+                        comp_pairs(0);
+                        if (gi + 1 < ngroups) {
+                            if (gi + 2 < ngroups) load_pairs(gi + 2, 0);
+                            comp_pairs(1);
+                        }
+                    }
+                    continue;
+                }
                 nb[lane] = make_float4(px - qx, py - qy, pz - qz, __int_as_float((h0 + lane < h) ? (idx >= 0 ? idx : -2) : -1));
                 wave_lds_order();
                 const int cols = min(64, h - h0);
