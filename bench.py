@@ -222,14 +222,20 @@ def main():
     from weasal_amd.trainer import InFlightLimiter
     limiter = InFlightLimiter(depth=4)
 
+    waits = {"prefetch": 0.0, "limiter": 0.0}
+
     def step(i):
         if prefetcher is not None:
-            batch = next(prefetcher)
+            tw0 = time.perf_counter()
+            batch = next(prefetcher)              # blocks while the side stream is still building this batch
+            waits["prefetch"] += time.perf_counter() - tw0
         else:
             pts, feats, labels, lens = inputs[i % nd]
             batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
         loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync, epoch=0 if args.contrast else None)
+        tw0 = time.perf_counter()
         limiter.tick(batch)          # bounds the host's run-ahead (4 steps); checks the K4G capacity flags off the hot path
+        waits["limiter"] += time.perf_counter() - tw0
         return loss
 
     # Untimed pre-warm before the W warm-up steps (allocator caches, lazy module loads), then the training
@@ -251,6 +257,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    waits["prefetch"] = waits["limiter"] = 0.0
     fused.timer_reset()
     fused.set_timed(True)            # HIP events around the K3 launches inside the block calls (launch stream)
     t0 = time.perf_counter()
@@ -279,7 +286,13 @@ def main():
         res = {"metric": "points/sec fwd+bwd KPFCNN on DALES spheres; achieved HBM GB/s on KPConv gather",
                "value": world * n_points * args.steps / dt, "unit": "points/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-               "host_issue_ms_per_step": 1000.0 * t_enqueued / args.steps, "higher_is_better": True,
+               # host side of the training thread: wall time to issue the K steps, and the same without the time it spent
+               # blocked (waiting for the side stream's next batch / for the GPU through the run-ahead limiter)
+               "host_issue_ms_per_step": 1000.0 * t_enqueued / args.steps,
+               "host_busy_ms_per_step": 1000.0 * (t_enqueued - waits["prefetch"] - waits["limiter"]) / args.steps,
+               "host_wait_prefetch_ms_per_step": 1000.0 * waits["prefetch"] / args.steps,
+               "host_wait_gpu_ms_per_step": 1000.0 * waits["limiter"] / args.steps,
+               "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
                "config": {"workload": wl["name"] + (", bf16 feature rows / fp32 accumulate / fp32 geometry" if bf16 else ", fp32")
                           + ", step = GPU pyramid + fwd + loss + bwd" + exch + " + SGD"
