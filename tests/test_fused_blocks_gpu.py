@@ -28,6 +28,12 @@ def _run(gpu, cfg, fused_on, seed=3, steps=1):
         np.random.seed(seed)
         torch.manual_seed(seed)
         net = KPFCNN(cfg, np.arange(9), []).to(gpu).train()
+        if not cfg.use_batch_norm:                         # learned biases (BatchNormBlock with use_bn False): make them count
+            gen = torch.Generator(device="cpu").manual_seed(17)
+            with torch.no_grad():
+                for name, p in net.named_parameters():
+                    if name.endswith(".bias"):
+                        p.copy_(0.1 * torch.randn(p.shape, generator=gen).to(gpu))
         opt = make_optimizer(net, cfg)
         pts, feats, labels, lens = synthetic.make_inputs(21, 3, 4000, 4.0, cfg.in_features_dim)
         np.random.seed(8)
@@ -44,11 +50,13 @@ def _run(gpu, cfg, fused_on, seed=3, steps=1):
         fused.MIN_ROWS = min_rows
 
 
-@pytest.mark.parametrize("cfg_name", ["DALESPLConfig", "Vaihingen3DPLConfig"])
-def test_block_calls_match_operator_path(gpu, cfg_name):
+@pytest.mark.parametrize("cfg_name,use_bn", [("DALESPLConfig", True), ("Vaihingen3DPLConfig", True), ("DALESPLConfig", False)])
+def test_block_calls_match_operator_path(gpu, cfg_name, use_bn):
+    """use_bn False: BatchNormBlock is a learned bias (blocks.py:465): b1 / bk / b2 / bs and their gradients are live"""
     from weasal_amd import config as wcfg
     cfg = getattr(wcfg, cfg_name)()
     cfg.dropout = 0.0
+    cfg.use_batch_norm = use_bn
     out_f, loss_f, g_f, p_f = _run(gpu, cfg, True)
     out_o, loss_o, g_o, p_o = _run(gpu, cfg, False)
     assert rel(out_f, out_o) < 2e-5
