@@ -1121,7 +1121,7 @@ int check_common(const void* q_pts, int64_t nq, const void* s_pts, int64_t ns, i
 // ---------------------------------------------------------------------------------------------
 constexpr int GRID_SLAB = 192;      // incoming pairs per support (the search reports rows up to 128)
 
-template <int K, int G, int MODE, bool VEC, typename T = float>
+template <int K, int G, int MODE, bool VEC, typename T = float, bool SORT = true>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
     const float* __restrict__ s_pts, int64_t ns, const CloudGrid* __restrict__ grids, int nb,
     const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
@@ -1211,8 +1211,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
         }
         wave_lds_sync();
         // ---- order by index: rank by counting (distinct indices), then permute through registers; only as many
-        //      entries per lane as the in-degree needs (1 for <= 64 incoming pairs)
-        {
+        //      entries per lane as the in-degree needs (1 for <= 64 incoming pairs).  SORT = false keeps the order of the
+        //      grid walk (cell run by cell run, compaction order inside a batch of 64): just as deterministic -- it depends
+        //      on the grid only -- but not the pair order of the transposed table, so dx then agrees with K4 to fp32
+        //      re-association (1e-6) instead of bit for bit; the counting loop it skips is ~ a third of this kernel's
+        //      instructions (the kernel is issue-bound: DESIGN.md section 4)
+        if (SORT) {
             float4 e[EPL];
             int rk[EPL];
 #pragma unroll
@@ -1337,6 +1341,8 @@ extern "C" int ws_kpconv_ablate;          // diagnostics (GeomParams::ablate); 0
 int ws_kpconv_ablate = 0;
 extern "C" int ws_kpconv_gs;              // diagnostics: > 0 forces the group size of the Ci = 32 matrix-core kernel
 int ws_kpconv_gs = 0;
+extern "C" int ws_kpconv_grid_sorted;     // 1: ws_kpconv_gather_bwd_x_grid sums the incoming pairs in index order (the pair order of
+int ws_kpconv_grid_sorted = 0;            //    the transposed table: bit-identical to ws_kpconv_gather_bwd_x); 0: in grid-walk order
 
 namespace {
 
@@ -1527,9 +1533,14 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
     WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
 #define WS_BWDG2(G, MODEV, VECV)                                                                                     \
     do {                                                                                                             \
-        if constexpr (F32 || VECV)                                                                                   \
-            kpconv_gather_bwd_x_grid_kernel<15, G, MODEV, VECV, T><<<grid, 256, 0, st>>>(                             \
-                s_pts, ns, grids, nb, cell_start, sorted, kl, r2, dwf, ci, kernel_points, deformed_kp, modulations, g, dx, order, overflow); \
+        if constexpr (F32 || VECV) {                                                                                 \
+            if (ws_kpconv_grid_sorted)                                                                               \
+                kpconv_gather_bwd_x_grid_kernel<15, G, MODEV, VECV, T, true><<<grid, 256, 0, st>>>(                   \
+                    s_pts, ns, grids, nb, cell_start, sorted, kl, r2, dwf, ci, kernel_points, deformed_kp, modulations, g, dx, order, overflow); \
+            else                                                                                                     \
+                kpconv_gather_bwd_x_grid_kernel<15, G, MODEV, VECV, T, false><<<grid, 256, 0, st>>>(                  \
+                    s_pts, ns, grids, nb, cell_start, sorted, kl, r2, dwf, ci, kernel_points, deformed_kp, modulations, g, dx, order, overflow); \
+        }                                                                                                            \
     } while (0)
 #define WS_BWDG(G)                                                                      \
     do {                                                                                \
