@@ -16,74 +16,139 @@ import torch
 from . import pyramid
 
 
+class _Replay:
+    """hands out pre-drawn uniform numbers through the `rand(n)` call of pyramid.batch_grid_subsampling"""
+
+    def __init__(self, values):
+        self.values = values
+        self.pos = 0
+
+    def rand(self, n):
+        out = self.values[self.pos:self.pos + n]
+        if out.shape[0] != n:
+            raise RuntimeError("prefetcher: more grid-orientation draws than pre-drawn for this batch")
+        self.pos += n
+        return out
+
+
 class PyramidPrefetcher:
     """Iterates PyramidBatch objects built ahead of time from `source`, an iterable of
-    (points, features, labels, lengths) with device tensors and host lengths."""
+    (points, features, labels, lengths) with device tensors and host lengths.
 
-    def __init__(self, config, source, neighborhood_limits=(), depth=2, random_grid_orient=True, device=None, seed=None):
-        """seed: the background thread draws the grid orientations from its own numpy RandomState(seed); None keeps the
-        global np.random stream (what the reference's workers use; then no other thread may draw from it meanwhile)"""
+    `workers` background threads, each with its OWN HIP stream and geometry workspaces, build alternate batches and hand
+    them over in source order.  One pyramid needs five host round trips (the subsampled sizes of the four levels and the
+    row widths of the searches must reach the host before the next level can be shaped), each of which waits for that
+    stream's queued kernels: a single builder is bound by that latency chain (~ 14 ms per DALES batch next to a training
+    stream, although its kernels take 4.7 ms), so the pipeline's rate, not the GPU, paced the training step.  Two builders
+    overlap their chains.  With `seed` each worker draws the grid orientations from its own RandomState(seed + worker);
+    without, the draws come from the global np.random in source order (taken under the source lock when a batch is handed to a
+    worker), i.e. the reference's stream exactly, whatever the number of workers."""
+
+    def __init__(self, config, source, neighborhood_limits=(), depth=2, random_grid_orient=True, device=None, seed=None,
+                 workers=None):
         self.config = config
-        self.rng = None if seed is None else __import__("numpy").random.RandomState(seed)
         self.limits = neighborhood_limits
         self.rgo = random_grid_orient
         self.source = iter(source)
-        self.queue = queue.Queue(maxsize=max(1, depth))
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.stream = torch.cuda.Stream(device=self.device)
+        import os
+        import numpy as np
+        self.workers = max(1, int(workers if workers is not None else os.environ.get("WEASAL_PREFETCH_WORKERS", "2")))
+        self.depth = max(1, depth)
+        prio = -1 if os.environ.get("WEASAL_PREFETCH_PRIORITY", "0") != "0" else 0
+        self.streams = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(self.workers)]
+        self.stream = self.streams[0]
+        self.seed = seed
+        self.rngs = [None if seed is None else np.random.RandomState(seed + w) for w in range(self.workers)]
         self.error = None
         self._stop = False
-        self.thread = threading.Thread(target=self._run, name="weasal-pyramid-prefetch", daemon=True)
-        self.thread.start()
+        self._src_lock = threading.Lock()          # source iteration and sequence numbers
+        self._cv = threading.Condition()           # finished batches, keyed by sequence number
+        self._done = {}
+        self._next_in = 0                          # next sequence number to hand to a worker
+        self._next_out = 0                         # next sequence number the consumer takes
+        self._exhausted = False
+        self.threads = [threading.Thread(target=self._run, args=(w,), name="weasal-pyramid-prefetch-%d" % w, daemon=True)
+                        for w in range(self.workers)]
+        self.thread = self.threads[0]
+        for t in self.threads:
+            t.start()
 
-    def _run(self):
+    def _take(self):
+        """-> (sequence number, item) or None when the source is exhausted; waits while the pipeline is `depth` ahead"""
+        with self._cv:
+            while not self._stop and self._next_in - self._next_out >= self.depth + self.workers - 1:
+                self._cv.wait(0.05)
+        with self._src_lock:
+            if self._stop or self._exhausted:
+                return None
+            try:
+                item = next(self.source)
+            except StopIteration:
+                self._exhausted = True
+                return None
+            seq = self._next_in
+            self._next_in += 1
+            rng = None
+            if self.rgo and self.seed is None:
+                # the reference's stream: the global np.random, consumed in SOURCE order whatever the workers do -- the
+                # draws of this batch (theta, phi, alpha per subsampled level, datasets/common.py:99-109) are taken here,
+                # under the source lock, and replayed by the worker
+                import numpy as np
+                nb = len(item[3])
+                rng = _Replay(np.random.rand(3 * nb * max(self.config.num_layers - 1, 0)))
+            return seq, item, rng
+
+    def _run(self, w):
         try:
             torch.cuda.set_device(self.device)
-            with torch.cuda.stream(self.stream):
-                for item in self.source:
-                    if self._stop:
+            with torch.cuda.stream(self.streams[w]):
+                while not self._stop:
+                    got = self._take()
+                    if got is None:
                         break
-                    points, features, labels, lengths = item
+                    seq, (points, features, labels, lengths), rng = got
                     batch = pyramid.build_batch(self.config, points, features, labels, lengths, self.limits, self.rgo,
-                                                rng=self.rng)
-                    while not self._stop:
-                        try:
-                            self.queue.put(batch, timeout=0.1)
-                            break
-                        except queue.Full:
-                            continue
+                                                rng=rng if rng is not None else self.rngs[w])
+                    with self._cv:
+                        self._done[seq] = batch
+                        self._cv.notify_all()
         except BaseException as e:   # surfaced to the consumer
             self.error = e
         finally:
             try:
-                self.stream.synchronize()               # nothing of this thread's scratch is in flight any more
+                self.streams[w].synchronize()           # nothing of this thread's scratch is in flight any more
                 from . import ops
                 ops.release_thread_workspaces(self.device)   # the thread owns its geometry workspaces: freed with it
             except Exception:
                 pass
-            while not self._stop:
-                try:
-                    self.queue.put(None, timeout=0.1)
-                    break
-                except queue.Full:
-                    continue
+            with self._cv:
+                self._cv.notify_all()
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        batch = self.queue.get()
-        if batch is None:
-            if self.error is not None:
-                raise self.error
-            raise StopIteration
-        return batch
+        with self._cv:
+            while True:
+                if self._next_out in self._done:
+                    batch = self._done.pop(self._next_out)
+                    self._next_out += 1
+                    self._cv.notify_all()
+                    return batch
+                if self.error is not None:
+                    raise self.error
+                alive = any(t.is_alive() for t in self.threads)
+                if (self._exhausted and self._next_out >= self._next_in) or (not alive and self._next_out not in self._done):
+                    if self.error is not None:
+                        raise self.error
+                    raise StopIteration
+                self._cv.wait(0.05)
 
     def close(self):
         self._stop = True
-        try:
-            while True:
-                self.queue.get_nowait()
-        except queue.Empty:
-            pass
-        self.thread.join(timeout=5)
+        with self._cv:
+            self._done.clear()
+            self._cv.notify_all()
+        for t in self.threads:
+            t.join(timeout=5)
