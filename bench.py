@@ -257,6 +257,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    if os.environ.get("WEASAL_STALL_DIAG"):
+        pyramid.ACTIVATE_STALLS = []
     waits["prefetch"] = waits["limiter"] = 0.0
     fused.timer_reset()
     fused.set_timed(True)            # HIP events around the K3 launches inside the block calls (launch stream)
@@ -277,6 +279,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if rank == 0 and pyramid.ACTIVATE_STALLS:
+        st = [a.elapsed_time(b) for a, b in pyramid.ACTIVATE_STALLS]
+        print("[bench] training stream waiting for the batch's pyramid at the hand-over: mean %.3f ms, max %.3f ms over %d steps"
+              % (float(np.mean(st)), float(np.max(st)), len(st)), file=sys.stderr)
     if rank == 0:
         ms = 1000.0 * dt / args.steps
         bf16 = getattr(cfg, 'feature_dtype', 'f32') == 'bf16'

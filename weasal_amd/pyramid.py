@@ -144,6 +144,9 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
             + [stacked_features, labels])
 
 
+ACTIVATE_STALLS = None       # set to a list to collect (event, event) pairs around the hand-over wait (bench.py --stall-diag)
+
+
 class PyramidBatch:
     """The `batch` object the blocks index (``.points/.neighbors/.pools/.upsamples/.lengths/
     .features/.labels``), built from the flat list like the reference's CustomBatch classes
@@ -225,7 +228,14 @@ class PyramidBatch:
         if self.features.is_cuda:
             stream = stream or torch.cuda.current_stream(self.features.device)
             if self.ready is not None:
-                stream.wait_event(self.ready)
+                if ACTIVATE_STALLS is not None:            # diagnostics: how long the consumer stream waits for the builder's stream
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    stream.wait_event(self.ready)
+                    e1.record(stream)
+                    ACTIVATE_STALLS.append((e0, e1))
+                else:
+                    stream.wait_event(self.ready)
                 for t in self._tensors():
                     if isinstance(t, torch.Tensor) and t.is_cuda:
                         t.record_stream(stream)
