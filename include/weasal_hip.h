@@ -475,6 +475,28 @@ int64_t ws_potentials_scratch_bytes(int64_t n);
 int ws_potentials_update(const float* pot_points, int64_t n, const double* h_center, double radius, double* potentials,
                          double* out_min, int64_t* out_argmin, void* scratch, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The two ends of the training step around the network (forward + backward + SGD).
+ * ws_softmax_ce_fwd / _bwd: models/architectures.py:362-373 (KPFCNN.loss) -- the label mapping (:362-365; lut [lut_n]
+ *   maps raw label values to class positions, its last entry is the spare -1 every out-of-table label takes; lut NULL =
+ *   labels are positions, < 0 ignored) and torch.nn.CrossEntropyLoss(weight = class_w or NULL, ignore_index = -1) over the
+ *   n rows of logits [n, c] (row pitch ldl), c <= 64: loss[0] = weighted mean over the valid rows, wsum[0] = sum of their
+ *   weights (both device floats; no valid row -> nan like the stock loss).  The backward takes d loss as a device
+ *   float (grad_loss[0]) so that nothing synchronises; rows with ignored labels get zeros.
+ * ws_sgd_step: utils/trainer_PseudoLabel.py:216-218 with the optimizer of :72-82 -- clip_grad_value_(clip_value; <= 0 =
+ *   off), weight decay, momentum buffer (first != 0: buf = g, the first step of torch.optim.SGD) and p -= lr * buf for
+ *   `count` tensors in one pass; h_params / h_grads / h_bufs / h_sizes are HOST arrays of device pointers / element counts
+ *   (one parameter group per call: lr, momentum and weight_decay are per group).  No dampening, no Nesterov.
+ * ------------------------------------------------------------------------------------------ */
+int64_t ws_softmax_ce_scratch_bytes(int64_t n);
+int ws_softmax_ce_fwd(const float* logits, int64_t n, int32_t c, int64_t ldl, const int64_t* labels, const int64_t* lut,
+                      int32_t lut_n, const float* class_w, float* loss, float* wsum, void* scratch, void* stream);
+int ws_softmax_ce_bwd(const float* logits, int64_t n, int32_t c, int64_t ldl, const int64_t* labels, const int64_t* lut,
+                      int32_t lut_n, const float* class_w, const float* grad_loss, const float* wsum, float* dlogits, int64_t ldd,
+                      void* stream);
+int ws_sgd_step(float* const* h_params, const float* const* h_grads, float* const* h_bufs, const int64_t* h_sizes, int32_t count,
+                float lr, float momentum, float weight_decay, float clip_value, int32_t first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

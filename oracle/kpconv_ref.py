@@ -100,14 +100,26 @@ def matmul_epilogue_ref(x, b, bias=None, residual=None, slope=None):
     return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
 
 
+def cross_entropy_ref(logits, labels, lut=None, weight=None):
+    """models/architectures.py:362-373: labels -> positions (-1 ignored), CrossEntropyLoss(weight, ignore_index=-1) over
+    the transposed, unsqueezed logits [1, C, N]"""
+    if lut is not None:
+        idx = torch.where((labels >= 0) & (labels < lut.shape[0] - 1), labels, torch.full_like(labels, lut.shape[0] - 1))
+        target = lut.to(labels.device)[idx]
+    else:
+        target = labels
+    return torch.nn.functional.cross_entropy(logits.transpose(0, 1).unsqueeze(0), target.unsqueeze(0), weight=weight,
+                                             ignore_index=-1)
+
+
 @contextlib.contextmanager
 def cpu_reference_mode():
     """Evaluate weasal_amd.blocks / architectures modules with the restatements above (CPU)."""
     from weasal_amd import ops
-    names = ("kpconv_gather", "max_pool", "closest_pool", "matmul", "linear", "matmul_epilogue")
+    names = ("kpconv_gather", "max_pool", "closest_pool", "matmul", "linear", "matmul_epilogue", "cross_entropy")
     saved = [getattr(ops, n) for n in names]
     for n, f in zip(names, (kpconv_gather_ref, max_pool_ref, closest_pool_ref, matmul_ref, linear_ref,
-                            matmul_epilogue_ref)):
+                            matmul_epilogue_ref, cross_entropy_ref)):
         setattr(ops, n, f)
     try:
         yield

@@ -1,0 +1,116 @@
+"""GPU parity of the two ends of the training step: the fused loss (ws_softmax_ce_fwd / _bwd, models/architectures.py:362-373)
+against the oracle's statement of the reference criterion on the CPU, and the fused parameter update (ws_sgd_step,
+utils/trainer_PseudoLabel.py:72-82,216-218) against torch.nn.utils.clip_grad_value_ + torch.optim.SGD on CPU copies.
+Tolerances: loss 1e-6 of max(|loss|, 1) (f32 sums in another order), gradients 1e-6 of the largest entry, parameters after three
+steps 1e-6 relative (the stock kernels may contract a * b + c into one rounding)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lut(valid, device):
+    vmax = int(max(valid))
+    lut = -torch.ones(vmax + 2, dtype=torch.int64)
+    for i, c in enumerate(sorted(valid)):
+        lut[c] = i
+    return lut.to(device)
+
+
+@pytest.mark.parametrize("n,c,weighted", [(5000, 9, False), (5000, 9, True), (257, 4, True), (1, 9, False), (70001, 64, False)])
+def test_cross_entropy_matches_the_reference_criterion(gpu, n, c, weighted):
+    from weasal_amd import ops
+    from oracle import kpconv_ref
+    rng = np.random.RandomState(3)
+    valid = list(range(1, c + 1))                                  # label values 1..c are classes, 0 and 99 are ignored
+    logits = torch.from_numpy((rng.randn(n, c) * 3).astype(np.float32))
+    labels = torch.from_numpy(rng.choice([0, 99] + valid, size=n).astype(np.int64))
+    labels[0] = valid[0]                                           # at least one valid row
+    w = torch.from_numpy(rng.uniform(0.5, 2.0, c).astype(np.float32)) if weighted else None
+    x_ref = logits.clone().requires_grad_(True)
+    loss_ref = kpconv_ref.cross_entropy_ref(x_ref, labels, _lut(valid, "cpu"), w)
+    (loss_ref * 1.7).backward()
+    x = logits.to(gpu).requires_grad_(True)
+    loss = ops.cross_entropy(x, labels.to(gpu), _lut(valid, gpu), None if w is None else w.to(gpu))
+    (loss * 1.7).backward()
+    # a row's term is logsumexp - x[t], a difference of O(|logit|) numbers: an ulp of those, so absolute for small losses
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-6 * max(abs(float(loss_ref.detach())), 1.0)
+    g, g_ref = x.grad.cpu(), x_ref.grad
+    assert float((g - g_ref).abs().max()) <= 1e-6 * float(g_ref.abs().max())
+    ignored = ~torch.isin(labels, torch.tensor(valid))
+    assert float(g[ignored].abs().sum()) == 0.0                    # ignored rows: exact zeros
+
+
+def test_cross_entropy_edge_cases(gpu):
+    from weasal_amd import ops, _lib
+    # labels already positions (no table), a strided logits view, every row ignored -> nan like the stock loss
+    rng = np.random.RandomState(4)
+    wide = torch.from_numpy(rng.randn(300, 16).astype(np.float32)).to(gpu)
+    x = wide[:, :9]
+    t = torch.from_numpy(rng.randint(-1, 9, 300).astype(np.int64))
+    ref = torch.nn.functional.cross_entropy(x.cpu(), t, ignore_index=-1)
+    got = ops.cross_entropy(x, t.to(gpu))
+    assert abs(float(got) - float(ref)) <= 1e-6 * abs(float(ref))
+    none = ops.cross_entropy(x, torch.full((300,), -1, dtype=torch.int64, device=gpu))
+    assert torch.isnan(none).item()
+    with pytest.raises(_lib.WeasalHipError):
+        ops.cross_entropy(x.cpu(), t)
+    with pytest.raises(_lib.WeasalHipError):
+        ops.cross_entropy(torch.zeros(4, 65, device=gpu), torch.zeros(4, dtype=torch.int64, device=gpu))
+
+
+def _params(rng, device):
+    shapes = [(1,), (3,), (5, 7), (4097,), (64, 15, 33), (100003,), (0,), (1024, 256)]
+    return [torch.nn.Parameter(torch.from_numpy(rng.randn(*s).astype(np.float32)).to(device)) for s in shapes]
+
+
+@pytest.mark.parametrize("momentum,wd,clip", [(0.98, 1e-3, 100.0), (0.9, 0.0, 0.05), (0.0, 1e-3, 0.0)])
+def test_fused_sgd_matches_clip_and_torch_sgd(gpu, momentum, wd, clip):
+    from weasal_amd.trainer import FusedSGD
+    rng = np.random.RandomState(5)
+    ps_ref = _params(rng, "cpu")
+    ps = [torch.nn.Parameter(p.detach().clone().to(gpu)) for p in ps_ref]
+    groups = lambda q: [{'params': q[:5]}, {'params': q[5:], 'lr': 0.003}]
+    ref = torch.optim.SGD(groups(ps_ref), lr=0.01, momentum=momentum, weight_decay=wd)
+    opt = FusedSGD(groups(ps), lr=0.01, momentum=momentum, weight_decay=wd)
+    for step in range(3):
+        for p_ref, p in zip(ps_ref, ps):
+            g = torch.from_numpy((rng.randn(*p_ref.shape) * (0.1 if step else 1.0)).astype(np.float32))
+            p_ref.grad = g.clone()
+            p.grad = g.to(gpu)
+        if step == 1:                                              # a parameter the graph skipped this step
+            ps_ref[2].grad = None
+            ps[2].grad = None
+        if clip > 0:
+            torch.nn.utils.clip_grad_value_([p for p in ps_ref if p.grad is not None], clip)
+        ref.step()
+        opt.step(clip_value=clip)
+        if step == 1:
+            opt.param_groups[0]['lr'] = ref.param_groups[0]['lr'] = 0.02      # what the scheduler does between epochs
+    for i, (p_ref, p) in enumerate(zip(ps_ref, ps)):
+        if p_ref.numel() == 0:
+            continue
+        err = float((p.detach().cpu() - p_ref.detach()).abs().max()) / float(p_ref.detach().abs().max())
+        assert err <= 1e-6, (i, err)
+        if momentum:
+            b, b_ref = opt.state[p]['momentum_buffer'].cpu(), ref.state[p_ref]['momentum_buffer']
+            assert float((b - b_ref).abs().max()) <= 1e-6 * float(b_ref.abs().max()), i
+    # the state is torch.optim.SGD's: it loads into the stock optimizer
+    stock = torch.optim.SGD(groups([torch.nn.Parameter(p.detach().clone()) for p in ps]), lr=0.01, momentum=momentum, weight_decay=wd)
+    stock.load_state_dict(opt.state_dict())
+
+
+def test_fused_sgd_hands_unsupported_cases_to_torch(gpu):
+    from weasal_amd.trainer import FusedSGD
+    p = torch.nn.Parameter(torch.ones(10, device=gpu))
+    q = torch.nn.Parameter(torch.ones(10, device=gpu))
+    a = FusedSGD([p], lr=0.1, momentum=0.9, nesterov=True)
+    b = torch.optim.SGD([q], lr=0.1, momentum=0.9, nesterov=True)
+    for _ in range(2):
+        p.grad = torch.full((10,), 3.0, device=gpu)
+        q.grad = torch.full((10,), 3.0, device=gpu)
+        torch.nn.utils.clip_grad_value_([q], 1.0)
+        a.step(clip_value=1.0)
+        b.step()
+    assert torch.equal(p.detach(), q.detach())

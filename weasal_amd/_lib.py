@@ -102,6 +102,10 @@ SIGNATURES = {
     "ws_project_confusion": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
     "ws_potentials_scratch_bytes": (_i64, [_i64]),
     "ws_potentials_update": (C.c_int, [_vp, _i64, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
+    "ws_softmax_ce_scratch_bytes": (_i64, [_i64]),
+    "ws_softmax_ce_fwd": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ws_softmax_ce_bwd": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "ws_sgd_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "ws_timer_reset": (C.c_int, []),
     "ws_timer_count": (C.c_int, []),
     "ws_timer_read": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),

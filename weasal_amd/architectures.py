@@ -165,26 +165,31 @@ class KPFCNN(nn.Module):
         x = self.head_mlp(x, batch)
         return self.head_softmax(x, batch)
 
-    def _targets(self, labels):
-        """labels -> class index in [0, C) or -1 for ignored labels (architectures.py:362-365)"""
-        # one table gather instead of the reference's loop of masked assignments (same mapping)
+    def _label_lut(self, device):
+        """label value -> class position table [vmax + 2] (architectures.py:362-365); the last, spare entry is the -1
+        that ignored / unlabeled values outside the table take"""
         lut = getattr(self, "_target_lut", None)
-        if lut is None or lut.device != labels.device:
+        if lut is None or lut.device != device:
             vmax = int(max(int(np.max(self.valid_labels)) if len(self.valid_labels) else 0, 0))
             lut = -torch.ones(vmax + 2, dtype=torch.int64)
             for i, c in enumerate(self.valid_labels):
                 if 0 <= int(c) <= vmax:
                     lut[int(c)] = i
-            lut = lut.to(labels.device)
+            lut = lut.to(device)
             self._target_lut = lut
-        # labels outside the table (ignored / unlabeled values) map to -1 through the last, spare entry
+        return lut
+
+    def _targets(self, labels):
+        """labels -> class index in [0, C) or -1 for ignored labels (architectures.py:362-365)"""
+        # one table gather instead of the reference's loop of masked assignments (same mapping)
+        lut = self._label_lut(labels.device)
         idx = torch.where((labels >= 0) & (labels < lut.shape[0] - 1), labels, torch.full_like(labels, lut.shape[0] - 1))
         return lut[idx]
 
     def loss(self, outputs, labels):
-        """cross entropy over [1, C, N] with ignore_index -1, plus the deformable regulariser"""
-        target = self._targets(labels)
-        self.output_loss = self.criterion(outputs.transpose(0, 1).unsqueeze(0), target.unsqueeze(0))
+        """cross entropy over [1, C, N] with ignore_index -1 (label mapping and criterion fused: ops.cross_entropy),
+        plus the deformable regulariser"""
+        self.output_loss = ops.cross_entropy(outputs, labels, self._label_lut(labels.device), self.criterion.weight)
         if self.deform_fitting_mode == 'point2point':
             self.reg_loss = p2p_fitting_regularizer(self)
         elif self.deform_fitting_mode == 'point2plane':

@@ -615,13 +615,35 @@ __global__ __launch_bounds__(256) void gemm_xty2_kernel(const TI* __restrict__ x
         float* out = partial + (int64_t)blockIdx.x * k * n;
 #pragma unroll
         for (int a = 0; a < KT; ++a)
+            if constexpr (NT == 2) {
+                // the two interleaved column tiles of a lane are adjacent columns: one 8-byte store per row (a wave
+                // instruction writes two full 256-byte row segments) when the row pitch allows it
+                const int col = n0 + 2 * idx;
+                if ((n & 1) == 0) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int col = n0 + NT * idx + i;
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = c0 + KT * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
+                        if (row < k && col + 1 < n)
+                            *reinterpret_cast<float2*>(out + (int64_t)row * n + col) = make_float2(acc[a][0][r], acc[a][1][r]);
+                    }
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = c0 + KT * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
-                    if (row < k && col < n) out[(int64_t)row * n + col] = acc[a][i][r];
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = c0 + KT * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
+                            if (row < k && col + i < n) out[(int64_t)row * n + col + i] = acc[a][i][r];
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int col = n0 + NT * idx + i;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = c0 + KT * ((r & 3) + 8 * (r >> 2) + 4 * h) + a;
+                        if (row < k && col < n) out[(int64_t)row * n + col] = acc[a][i][r];
+                    }
                 }
             }
     }
@@ -656,6 +678,31 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
+// the same sum for LARGE outputs of few chunks (dW of the deep levels: k n up to 4 M elements, <= ~16 chunks): a thread owns
+// four consecutive elements and adds the chunks in order 0, 1, 2, ... (four 16-byte loads in flight)
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ partial, int64_t elems, int chunks,
+                                                                    float* __restrict__ out)
+{
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= elems) return;
+    const float4* p = reinterpret_cast<const float4*>(partial + e);
+    const int64_t st = elems / 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c = 0;
+    for (; c + 3 < chunks; c += 4) {
+        const float4 v0 = p[(int64_t)c * st], v1 = p[(int64_t)(c + 1) * st], v2 = p[(int64_t)(c + 2) * st], v3 = p[(int64_t)(c + 3) * st];
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+        s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+        s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; c < chunks; ++c) {
+        const float4 v = p[(int64_t)c * st];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + e) = s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // dz = LeakyReLU'(y) * dy and the column sums of dz (the bias gradient of a BatchNormBlock,
 // models/blocks.py:465) in ONE pass over [m, n]: partial column sums per row chunk (threads = column
@@ -676,8 +723,8 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __rest
     const int rl = t / per, cgl = t % per;
     const int64_t mbeg = (int64_t)blockIdx.x * chunk;
     const int64_t mend = mbeg + chunk < m ? mbeg + chunk : m;
-    for (int cg0 = 0; cg0 < ncg; cg0 += per) {
-        const int cg = cg0 + cgl;
+    {   // one pass of `per` column groups per workgroup row of the grid (blockIdx.y)
+        const int cg = (int)blockIdx.y * per + cgl;
         const int col = cg * V;
         float s[V];
 #pragma unroll
@@ -738,19 +785,42 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __rest
 int64_t colsum_chunk(int64_t m)
 {
     int64_t c = ws_ceil_div(m, 768);
-    return c < 128 ? 128 : c;                           // <= 768 chunks (three workgroups per CU) of >= 128 rows
+    return c < 16 ? 16 : c;                             // <= 768 chunks (three workgroups per CU) of >= 16 rows
 }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// chunk sums -> out: the wide form for large outputs of few chunks, the grouped form otherwise
+void launch_reduce_partials(const float* partial, int64_t elems, int chunks, float* out, hipStream_t st)
+{
+    if (elems >= 65536 && chunks <= 64 && elems % 4 == 0 && al16(partial) && al16(out))
+        reduce_partials_wide_kernel<<<(unsigned)ws_ceil_div(elems, 1024), 256, 0, st>>>(partial, elems, chunks, out);
+    else
+        reduce_partials_kernel<<<(unsigned)ws_ceil_div(elems, 32), 256, 0, st>>>(partial, elems, chunks, out);
+}
+
 int64_t xty_chunk(int64_t m, int k, int n)
 {
-    (void)k; (void)n;
-    // <= 256 chunks, a multiple of BK rows each, at least 512 rows (keeps >= 256 workgroups in
-    // flight for the tall layers even when K fits one k-tile)
-    int64_t c = ws_ceil_div(m, 256);
-    if (c < 512) c = 512;
-    return ws_ceil_div(c, BK) * BK;
+    if (m >= 32768) {
+        // tall operands: <= 256 chunks, a multiple of BK rows each, at least 512 rows (keeps >= 256 workgroups in
+        // flight even when K fits one k-tile)
+        int64_t c = ws_ceil_div(m, 256);
+        if (c < 512) c = 512;
+        return ws_ceil_div(c, BK) * BK;
+    }
+    // short operands (the deep pyramid levels): one chunk is a serial chain of m / 2 MFMA steps per wave, so the rows are
+    // split until the chain (A / chunks) balances the write + re-read of the partial outputs (B * chunks):
+    //   A = m/2 steps x 4 tiles x 64 cycles at 2.4 GHz,  B = 2 x 4 k n bytes at ~2 TB/s (measured: scattered partial stores),  chunks = sqrt(A / B),
+    // at most 256 workgroups (tiles of 128 x 128 outputs x chunks: one per CU -- beyond that the MFMA pipes are shared and
+    // more chunks only add partial traffic; 257..511 workgroups would double the time) and at least 32 rows per chunk.
+    const double a_us = (double)m * 0.5 * 4.0 * 64.0 / 2400.0;
+    const double b_us = 16.0 * (double)k * (double)n / 4.0e6;
+    const int64_t tiles = ws_ceil_div(k, 128) * ws_ceil_div(n, 128);
+    int64_t chunks = (int64_t)(__builtin_sqrt(a_us / b_us) + 0.5);
+    if (chunks > 256 / tiles) chunks = 256 / tiles;
+    if (chunks > m / 32) chunks = m / 32;
+    if (chunks < 1) chunks = 1;
+    return ws_ceil_div(ws_ceil_div(m, chunks), BK) * BK;
 }
 
 }  // namespace
@@ -869,9 +939,11 @@ int ws_act_bwd_colsum(const float* dy, int64_t m, int32_t n, int64_t lddy, const
     float* partial = colsum ? (chunks == 1 ? colsum : (float*)scratch) : nullptr;
     const bool vec = n % 4 == 0 && al16(dy) && lddy % 4 == 0 && (!y || (al16(y) && ldy % 4 == 0 && al16(dz) && lddz % 4 == 0));
     if (vec)
-        act_bwd_colsum_kernel<4><<<chunks, 256, 0, st>>>(dy, y, m, n, lddy, ldy, slope, dz, lddz, partial, chunk);
+        act_bwd_colsum_kernel<4><<<dim3(chunks, (unsigned)ws_ceil_div(ws_ceil_div(n, 4), 256)), 256, 0, st>>>(
+            dy, y, m, n, lddy, ldy, slope, dz, lddz, partial, chunk);
     else
-        act_bwd_colsum_kernel<1><<<chunks, 256, 0, st>>>(dy, y, m, n, lddy, ldy, slope, dz, lddz, partial, chunk);
+        act_bwd_colsum_kernel<1><<<dim3(chunks, (unsigned)ws_ceil_div(n, 256)), 256, 0, st>>>(dy, y, m, n, lddy, ldy, slope, dz, lddz,
+                                                                                              partial, chunk);
     WS_LAUNCH_CHECK();
     if (colsum && chunks > 1) {
         reduce_partials_kernel<<<(unsigned)ws_ceil_div(n, 32), 256, 0, st>>>(partial, n, chunks, colsum);
@@ -974,7 +1046,7 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
     WS_LAUNCH_CHECK();
     if (chunks > 1) {
         const int64_t elems = (int64_t)k * n;
-        reduce_partials_kernel<<<(unsigned)ws_ceil_div(elems, 32), 256, 0, st>>>(partial, elems, chunks, out);
+        launch_reduce_partials(partial, elems, chunks, out, st);
         WS_LAUNCH_CHECK();
     }
     return WS_OK;
@@ -1025,7 +1097,7 @@ int ws_gemm_xty_bf16(const uint16_t* x, int64_t m, int32_t k, int64_t ldx, const
     WS_LAUNCH_CHECK();
     if (chunks > 1) {
         const int64_t elems = (int64_t)k * n;
-        reduce_partials_kernel<<<(unsigned)ws_ceil_div(elems, 32), 256, 0, st>>>(partial, elems, chunks, out);
+        launch_reduce_partials(partial, elems, chunks, out, st);
         WS_LAUNCH_CHECK();
     }
     return WS_OK;

@@ -206,10 +206,11 @@ def _geometry(conv, q_pts, s_pts, inds, strided):
     return g
 
 
-# below this many rows a layer is launch-bound and its dense products are too short for the tall-skinny MFMA kernels
-# (split-K + epilogue + reduction launches): measured 0.6 ms per DALES step slower than the operator path, which hands
-# those products to the library GEMM
-MIN_ROWS = int(os.environ.get("WEASAL_FUSED_MIN_ROWS", "4096"))
+# A/B switch (diagnostics): layers with fewer rows take the operator path.  Default 0 = every layer is a block call: with
+# the row-split dW reduction and the per-CU chunking of the short products (gemm.hip: xty_chunk, colsum_chunk) the deep
+# levels cost the same GPU time as the library GEMM they used to be handed to (14.28 vs 14.21 ms per DALES step) and
+# the host issues a step in 4.3 instead of 7.5 ms.
+MIN_ROWS = int(os.environ.get("WEASAL_FUSED_MIN_ROWS", "0"))
 
 
 def kpblock_eligible(block, x):

@@ -266,7 +266,7 @@ def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linea
 # tall-skinny GEMMs (unary MLPs and the kernel contraction) on the f32 MFMA
 # ------------------------------------------------------------------------------------------------
 FUSED_EPILOGUE = os.environ.get("WEASAL_FUSED_EPILOGUE", "1") != "0"   # A/B switch (diagnostics)
-GEMM_MIN_ROWS = int(os.environ.get("WEASAL_GEMM_MIN_ROWS", "4096"))     # below this the operand is no longer "tall": plain torch.matmul (rocBLAS)
+GEMM_MIN_ROWS = int(os.environ.get("WEASAL_GEMM_MIN_ROWS", "0"))        # A/B switch (diagnostics): fewer rows -> torch.matmul (library GEMM); default: never
 XTY_MIN_ROWS = 0         # A/B switch: rows below which dW = x^T dy goes to rocBLAS (in the training step the MFMA
                          # reduction is ahead at every level that reaches it: 0.42 ms vs 0.54 ms per step at M = 10 257)
 
@@ -499,8 +499,8 @@ class _MatmulEpilogue(torch.autograd.Function):
 
 
 def matmul_epilogue(x, b, bias=None, residual=None, slope=None, out_f32=False):
-    """act(x @ b + bias + residual): one MFMA kernel for tall operands (b is [K,N]); short operands
-    (deep layers, < GEMM_MIN_ROWS rows) go to rocBLAS through torch -- still on the GPU.
+    """act(x @ b + bias + residual): one MFMA kernel (b is [K,N]; short, deep products of the deep layers split K).
+    GEMM_MIN_ROWS > 0 (diagnostics) hands operands with fewer rows to the library GEMM through torch.
     bf16 rows (x.dtype bfloat16) always take the bf16 MFMA kernel; out_f32 keeps its output in f32."""
     _need_cuda(x, b)
     if x.dtype == torch.bfloat16 and x.dim() == 2:
@@ -523,7 +523,7 @@ def matmul_epilogue(x, b, bias=None, residual=None, slope=None, out_f32=False):
 
 
 def matmul(x, b):
-    """x [M,K] @ b [K,N]: the MFMA kernels for tall operands, rocBLAS (torch.matmul on the GPU) for short ones"""
+    """x [M,K] @ b [K,N] on the MFMA kernels of this library (GEMM_MIN_ROWS > 0: diagnostics switch to the library GEMM)"""
     _need_cuda(x, b)
     if x.dtype == torch.bfloat16 and x.dim() == 2 and b.dim() == 2:
         return _MatmulEpilogueBF16.apply(x, b, None, None, None, False)
@@ -920,6 +920,46 @@ class _ContrastRows(torch.autograd.Function):
                                        ptr(rowmax), ptr(den), ptr(npos), ptr(g), ptr(d_on), ptr(d_xs), ptr(scratch),
                                        current_stream()))
         return d_on, d_xs, None, None, None, None, None
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    """label mapping + weighted cross entropy with ignore_index -1 (ws_softmax_ce_fwd / _bwd): scalar loss"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, lut, weight):
+        lib = _lib.lib()
+        x = logits if (logits.stride(1) == 1 and logits.stride(0) >= logits.shape[1]) else logits.contiguous()
+        n, c = x.shape
+        labels = labels.to(torch.int64).contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=x.device)          # loss, sum of weights
+        scratch = torch.empty(lib.ws_softmax_ce_scratch_bytes(n), dtype=torch.uint8, device=x.device)
+        check(lib.ws_softmax_ce_fwd(ptr(x), n, c, x.stride(0), ptr(labels), ptr(lut), 0 if lut is None else lut.shape[0],
+                                    ptr(weight), ptr(out), out.data_ptr() + 4, ptr(scratch), current_stream()))
+        ctx.save_for_backward(x, labels, lut, weight, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.lib()
+        x, labels, lut, weight, out = ctx.saved_tensors
+        n, c = x.shape
+        g = g.to(torch.float32).contiguous()
+        d = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        check(lib.ws_softmax_ce_bwd(ptr(x), n, c, x.stride(0), ptr(labels), ptr(lut), 0 if lut is None else lut.shape[0],
+                                    ptr(weight), ptr(g), out.data_ptr() + 4, ptr(d), c, current_stream()))
+        return d, None, None, None
+
+
+def cross_entropy(logits, labels, lut=None, weight=None):
+    """KPFCNN.loss's criterion (models/architectures.py:362-373): `lut` [V+2] int64 maps raw label values to class
+    positions (last entry: the spare -1 of out-of-table labels; None = labels are positions already, < 0 ignored), then
+    CrossEntropyLoss(weight, ignore_index=-1) over the rows of logits [N, C] -- one fused pass each way"""
+    _need_cuda(logits, labels)
+    if logits.dim() != 2 or logits.dtype != torch.float32:
+        raise _lib.WeasalHipError("cross_entropy takes float32 logits [N, C] (got %s %s)" % (logits.dtype, tuple(logits.shape)))
+    lut = None if lut is None else lut.to(device=logits.device, dtype=torch.int64).contiguous()
+    weight = None if weight is None else weight.to(device=logits.device, dtype=torch.float32).contiguous()
+    return _SoftmaxCE.apply(logits, labels, lut, weight)
 
 
 def contrast_rows(on, xs, slc_idx, certain, lbl, temperature, eps):

@@ -11,16 +11,70 @@ and are deliberately not reproduced.
 import torch
 
 
+class FusedSGD(torch.optim.SGD):
+    """torch.optim.SGD (same constructor, param_groups, state / state_dict: `momentum_buffer` per parameter) whose step on
+    GPU parameters is ONE pass of the HIP kernel ws_sgd_step per parameter group -- value clipping
+    (torch.nn.utils.clip_grad_value_, trainer_PseudoLabel.py:216), weight decay, momentum and the update read and write
+    every element once, instead of a clamp and three `foreach` passes.  Anything the kernel does not cover (CPU
+    parameters as in the gloo / oracle tests, Nesterov, dampening, maximize, non-f32 or sparse gradients) takes
+    torch's own step after the same clipping."""
+
+    def _fusable(self, group, params):
+        if group.get('nesterov') or group.get('dampening', 0) != 0 or group.get('maximize'):
+            return False
+        for p in params:
+            g = p.grad
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32
+                    and not g.is_sparse and g.is_contiguous() and g.device == p.device):
+                return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None, clip_value=0.0):
+        import ctypes
+        from . import _lib
+        groups = [(g, [p for p in g['params'] if p.grad is not None]) for g in self.param_groups]
+        if closure is not None or not all(self._fusable(g, ps) for g, ps in groups if ps):
+            if clip_value and clip_value > 0:
+                torch.nn.utils.clip_grad_value_([p for _, ps in groups for p in ps], clip_value)
+            return super().step(closure)
+        lib = _lib.lib()
+        for group, params in groups:
+            momentum = float(group['momentum'])
+            # parameters without a momentum buffer yet take torch's first step (buf = g): normally all of them or none
+            fresh = [p for p in params if self.state[p].get('momentum_buffer') is None] if momentum != 0 else []
+            seasoned = [p for p in params if self.state[p].get('momentum_buffer') is not None] if momentum != 0 else params
+            for first, sel in ((True, fresh), (False, seasoned)):
+                if not sel:
+                    continue
+                with torch.cuda.device(sel[0].device):
+                    n = len(sel)
+                    arr = ctypes.c_void_p * n
+                    if momentum != 0:
+                        if first:
+                            for p in sel:
+                                self.state[p]['momentum_buffer'] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                        bufs = arr(*[self.state[p]['momentum_buffer'].data_ptr() for p in sel])
+                    else:
+                        bufs = None
+                    _lib.check(lib.ws_sgd_step(arr(*[p.data_ptr() for p in sel]), arr(*[p.grad.data_ptr() for p in sel]), bufs,
+                                               (ctypes.c_int64 * n)(*[p.numel() for p in sel]), n, float(group['lr']), momentum,
+                                               float(group['weight_decay']), float(clip_value or 0.0), int(first),
+                                               _lib.current_stream()))
+        return None
+
+
 def make_optimizer(net, config):
-    """SGD with a second parameter group for the deformable offsets (trainer_PseudoLabel.py:80-87)"""
+    """SGD with a second parameter group for the deformable offsets (trainer_PseudoLabel.py:80-87); on the GPU the
+    step is the fused kernel of FusedSGD"""
     deform_params = [v for k, v in net.named_parameters() if 'offset' in k]
     other_params = [v for k, v in net.named_parameters() if 'offset' not in k]
     deform_lr = config.learning_rate * config.deform_lr_factor
-    # foreach: same arithmetic, one multi-tensor launch per group for zero_grad and step instead of one per parameter
+    # foreach: for the cases FusedSGD hands to torch (same arithmetic, multi-tensor launches)
     foreach = bool(other_params) and other_params[0].is_cuda
-    return torch.optim.SGD([{'params': other_params}, {'params': deform_params, 'lr': deform_lr}],
-                           lr=config.learning_rate, momentum=config.momentum,
-                           weight_decay=config.weight_decay, foreach=foreach or None)
+    return FusedSGD([{'params': other_params}, {'params': deform_params, 'lr': deform_lr}],
+                    lr=config.learning_rate, momentum=config.momentum,
+                    weight_decay=config.weight_decay, foreach=foreach or None)
 
 
 def train_step(net, optimizer, batch, config, grad_sync=None, epoch=None):
@@ -39,6 +93,9 @@ def train_step(net, optimizer, batch, config, grad_sync=None, epoch=None):
     loss.backward()
     if grad_sync is not None:
         grad_sync(net)
+    if isinstance(optimizer, FusedSGD):
+        optimizer.step(clip_value=config.grad_clip_norm)     # clip + weight decay + momentum + update in one pass
+        return loss, outputs
     if config.grad_clip_norm > 0:
         params = getattr(net, "_param_list", None)
         if params is None:                   # the parameter set is static: no module-tree walk per step
