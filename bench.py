@@ -270,6 +270,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    limiter.finish()                 # the K4G capacity flags of the last steps (outside the timed region: everything has completed)
     timer.enabled = False
     fused.set_timed(False)
     if prefetcher is not None:
@@ -350,6 +351,8 @@ def main():
             # batch to batch with the random grid orientation: rounded to two significant digits)
             agg = {}
             for k, v in summ.items():
+                if k[1] < 4096:       # the deep levels (a few hundred rows, H varying from batch to batch) would only clutter the line
+                    continue
                 nr = int(float("%.2g" % k[1]))
                 key = "%s N~%d H=%d C=%d" % (k[0], nr, k[2], k[3])
                 a = agg.setdefault(key, [0.0, 0])

@@ -243,6 +243,21 @@ int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid
                                 float extent, int32_t influence, int32_t aggregation, const int32_t* order, float* dx,
                                 int32_t* overflow, void* stream);
 
+/* K4 / K4G with the activation backward of the preceding unary block folded into the store: dx * LeakyReLU'(gate_y),
+ * gate_y [ns, ci] = that block's activated output (this layer's input x); gate_y NULL = the plain entries.
+ * Replaces the autograd of nn.LeakyReLU between unary1 and KPConv (models/blocks.py:676-683). */
+int ws_kpconv_gather_bwd_x_gated(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                                 const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
+                                 const float* dwf, int32_t ci, const float* kernel_points, int32_t k,
+                                 const float* deformed_kp, const float* modulations, float extent,
+                                 int32_t influence, int32_t aggregation, const int32_t* order, const float* gate_y,
+                                 float gate_slope, float* dx, void* stream);
+int ws_kpconv_gather_bwd_x_grid_gated(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                      const uint64_t* key_last, float radius, const float* dwf, int32_t ci,
+                                      const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                                      float extent, int32_t influence, int32_t aggregation, const int32_t* order,
+                                      const float* gate_y, float gate_slope, float* dx, int32_t* overflow, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Grid subsampling -- replaces cpp_wrappers/cpp_subsampling (grid_subsampling.subsample_batch /
  * subsample, wrapper.cpp:62-333,338-566 -> grid_subsampling.cpp:5-106,109-211).
@@ -445,6 +460,18 @@ int ws_gemm_xb_epilogue_strided(const float* x, int64_t m, int32_t k, int64_t ld
                                 int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
                                 int32_t act, float slope, float* y, int64_t ldy, void* scratch, int64_t scratch_bytes,
                                 void* stream);
+
+/* The same product with multiplicative gates on the epilogue (after bias / residual / activation):
+ *   gate_y [m, n] (pitch ldg, NULL = none): y *= LeakyReLU'(gate_y) = (gate_y > 0 ? 1 : gate_slope) -- when this product is the
+ *     gradient dX = dY W^T of a layer whose input came out of a LeakyReLU, gate_y is that activated tensor and the
+ *     activation backward (models/blocks.py:473-507, autograd of nn.LeakyReLU) costs no pass of its own;
+ *   mask [m, n] bytes (pitch ldm, NULL = none): y = mask ? y * mask_scale : 0 -- nn.Dropout (models/architectures.py:354-356),
+ *     forward on the activated output and backward on the gradient. */
+int ws_gemm_xb_gated_strided(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride,
+                             int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
+                             int32_t act, float slope, const float* gate_y, int64_t ldg, float gate_slope, const uint8_t* mask,
+                             int64_t ldm, float mask_scale, float* y, int64_t ldy, void* scratch, int64_t scratch_bytes,
+                             void* stream);
 
 /* HIP-event timing of selected kernel launches inside the block calls (bench.py's roofline figure): events are
  * recorded on the launch stream around the K3 launch of blocks with timed = 1.  ws_timer_read synchronises on the

@@ -240,3 +240,66 @@ def test_gemm_splitk_and_wave_grids_through_the_c_abi(gpu, m, k, n, ep):
     assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 5e-6
     if m < 32768 and k >= 512:
         assert sb > 0          # these shapes are the ones that split
+
+
+@pytest.mark.parametrize("m,k,n,gated,masked", [(5000, 128, 32, True, False), (5000, 128, 128, True, True), (300, 2048, 512, True, True),
+                                                 (70001, 9, 128, False, True), (1000, 64, 64, False, False)])
+def test_gemm_epilogue_gates_through_the_c_abi(gpu, m, k, n, gated, masked):
+    """ws_gemm_xb_gated_strided: LeakyReLU'(gate_y) and the dropout mask applied after bias / residual / activation --
+    rows-on-lanes kernel, its split-K form (300 x 2048) and the LDS-staged kernel (k = 9) -- against float64"""
+    from weasal_amd import _lib
+    from weasal_amd._lib import check, current_stream, ptr
+    lib = _lib.lib()
+    torch.manual_seed(m + n)
+    x = torch.randn(m, k, device=gpu)
+    b = torch.randn(k, n, device=gpu) / k ** 0.5
+    bias = torch.randn(n, device=gpu)
+    res = torch.randn(m, n, device=gpu)
+    gy = torch.randn(m, n, device=gpu) if gated else None
+    mask = (torch.rand(m, n, device=gpu) < 0.5).to(torch.uint8) if masked else None
+    y = torch.empty(m, n, device=gpu)
+    sb = lib.ws_gemm_xb_scratch_bytes(m, k, n)
+    scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=gpu)
+    check(lib.ws_gemm_xb_gated_strided(ptr(x), m, k, k, ptr(b), n, 1, n, ptr(bias), ptr(res), n, 1, 0.1, ptr(gy), n, 0.1, ptr(mask), n, 2.0,
+                                       ptr(y), n, ptr(scratch) if sb else None, sb, current_stream()))
+    ref = torch.nn.functional.leaky_relu(x.double() @ b.double() + bias.double() + res.double(), 0.1)
+    if gated:
+        ref = ref * torch.where(gy > 0, 1.0, 0.1).double()
+    if masked:
+        ref = ref * mask.double() * 2.0
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 5e-6
+
+
+def test_gated_gather_backward_is_the_plain_one_times_the_activation_derivative(gpu):
+    """ws_kpconv_gather_bwd_x_gated / _grid_gated == ws_kpconv_gather_bwd_x / _grid followed by * LeakyReLU'(gate_y), bit for bit"""
+    from weasal_amd import _lib, ops
+    from weasal_amd._lib import check, current_stream, ptr
+    from conftest import sphere
+    lib = _lib.lib()
+    rng = np.random.RandomState(11)
+    pts = torch.from_numpy(sphere(rng, 6000, 2.0)).to(gpu)
+    lens = [6000]
+    radius, extent, ci = 0.25, 0.12, 32
+    searches = ops.DeferredSearches(gpu)
+    _, _, grid = searches.add(pts, pts, lens, lens, radius, 40, want_grid=True)
+    inds, = searches.finish()
+    assert 1 < inds.shape[1] <= 40 and searches.last_counts[0] <= 128
+    kp = torch.from_numpy((rng.randn(15, 3) * 0.08).astype(np.float32)).to(gpu)
+    dwf = torch.randn(6000, 15 * ci, device=gpu)
+    gate = torch.randn(6000, ci, device=gpu)
+    table = ops.transposed_table(inds, 6000)
+    plain, gated = torch.empty(6000, ci, device=gpu), torch.empty(6000, ci, device=gpu)
+    check(lib.ws_kpconv_gather_bwd_x(ptr(pts), 6000, ptr(pts), 6000, ptr(inds), inds.shape[1], ptr(table.offsets), ptr(table.pairs), ptr(dwf),
+                                     ci, ptr(kp), 15, None, None, extent, 0, 0, None, ptr(plain), current_stream()))
+    check(lib.ws_kpconv_gather_bwd_x_gated(ptr(pts), 6000, ptr(pts), 6000, ptr(inds), inds.shape[1], ptr(table.offsets), ptr(table.pairs),
+                                           ptr(dwf), ci, ptr(kp), 15, None, None, extent, 0, 0, None, ptr(gate), 0.1, ptr(gated),
+                                           current_stream()))
+    assert torch.equal(gated, plain * torch.where(gate > 0, 1.0, 0.1).to(plain.dtype))
+    plain_g, gated_g = torch.empty(6000, ci, device=gpu), torch.empty(6000, ci, device=gpu)
+    check(lib.ws_kpconv_gather_bwd_x_grid(ptr(pts), 6000, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last), radius, ptr(dwf), ci,
+                                          ptr(kp), 15, None, None, extent, 0, 0, None, ptr(plain_g), ptr(grid.overflow), current_stream()))
+    check(lib.ws_kpconv_gather_bwd_x_grid_gated(ptr(pts), 6000, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last), radius, ptr(dwf),
+                                                ci, ptr(kp), 15, None, None, extent, 0, 0, None, ptr(gate), 0.1, ptr(gated_g),
+                                                ptr(grid.overflow), current_stream()))
+    assert torch.equal(gated_g, plain_g * torch.where(gate > 0, 1.0, 0.1).to(plain_g.dtype))
+    assert int(grid.overflow.item()) == 0

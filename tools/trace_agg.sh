@@ -6,7 +6,7 @@ cd $R
 tag=$1; shift
 for kv in "$@"; do export "$kv"; done
 rm -rf /tmp/ta_$tag
-rocprofv3 --kernel-trace --output-format csv -d /tmp/ta_$tag -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r2_ta_${tag}_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d /tmp/ta_$tag -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS > gpurun_out/r2_ta_${tag}_bench.json 2>/dev/null
 python3 - $tag <<'PY'
 import csv,glob,collections,re,sys
 tag=sys.argv[1]

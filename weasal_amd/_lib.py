@@ -98,6 +98,12 @@ SIGNATURES = {
     "ws_upunary_bwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ws_gemm_xb_epilogue_strided": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _i64,
                                               _vp, _i64, _vp]),
+    "ws_gemm_xb_gated_strided": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _f32, _vp, _i64, _f32,
+                                           _vp, _i64, _f32, _vp, _i64, _vp, _i64, _vp]),
+    "ws_kpconv_gather_bwd_x_gated": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32,
+                                              _vp, _vp, _f32, _i32, _i32, _vp, _vp, _f32, _vp, _vp]),
+    "ws_kpconv_gather_bwd_x_grid_gated": (C.c_int, [_vp, _i64, _vp, _i32, _i64, _vp, C.c_float, _vp, _i32, _vp, _i32, _vp, _vp,
+                                                    C.c_float, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp]),
     "ws_vote_update": (C.c_int, [_vp, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _f32, _vp]),
     "ws_project_confusion": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
     "ws_potentials_scratch_bytes": (_i64, [_i64]),

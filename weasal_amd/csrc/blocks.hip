@@ -10,6 +10,9 @@
 
 #include "ws_common.h"
 
+// diagnostics switch (WEASAL_BLOCK_GATES=0): activation backward as separate passes instead of epilogue / store gates
+extern "C" int ws_block_gates = 1;
+
 namespace {
 
 struct Arena {
@@ -189,6 +192,7 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         if (d->dfeat && ns > 0) WS_HIP(hipMemsetAsync(d->dfeat, 0, sizeof(float) * (size_t)ns * d->in_dim, st));
         return WS_OK;
     }
+    bool gated2 = false;
     const float* sc_res = nullptr;          // the shortcut's gradient w.r.t. feat rows [ns,in_dim]
     const float* gin = d->dout;             // gradient entering the convolution's activation
     const float* yconv = d->out;
@@ -215,32 +219,39 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
                 sc_res = dsc;
             }
         }
-        // dx2 = dz @ w2
-        WS_TRY(ws_gemm_xb_epilogue_strided(dz, nq, d->out_dim, d->out_dim, d->w2, d->conv_out, 1, d->conv_out, nullptr, nullptr, 0, 0, 0.0f,
-                                           g2, d->conv_out, tmp, tmp_bytes, st));
+        // dx2 = dz @ w2; without a bias gradient to sum (use_bn: BatchNormBlock is an identity, blocks.py:453-463) the
+        // activation backward of the convolution's LeakyReLU rides on the epilogue: dz2 = dx2 * lrelu'(x2)
+        gated2 = !d->dbk && ws_block_gates;
+        WS_TRY(ws_gemm_xb_gated_strided(dz, nq, d->out_dim, d->out_dim, d->w2, d->conv_out, 1, d->conv_out, nullptr, nullptr, 0, 0, 0.0f,
+                                        gated2 ? d->x2 : nullptr, d->conv_out, d->slope, nullptr, 0, 0.0f, g2, d->conv_out, tmp, tmp_bytes,
+                                        st));
         gin = g2;
         yconv = d->x2;
     }
     // dz2 = g * lrelu'(x2), dbk
-    WS_TRY(ws_act_bwd_colsum(gin, nq, d->conv_out, d->conv_out, yconv, d->conv_out, d->slope, g2, d->conv_out, d->dbk, tmp, st));
+    if (!gated2)
+        WS_TRY(ws_act_bwd_colsum(gin, nq, d->conv_out, d->conv_out, yconv, d->conv_out, d->slope, g2, d->conv_out, d->dbk, tmp, st));
     WS_TRY(ws_gemm_xty(d->wf, nq, kc, kc, g2, d->conv_out, d->conv_out, d->dwk, tmp, st));
     if (!need_dx1) return WS_OK;
     // dwf = dz2 @ wk^T
     WS_TRY(linear_fwd(lk, g2, nq, d->conv_out, nullptr, nullptr, 0, 0, 0.0f, dwf, trk, tmp, tmp_bytes, st));
     float* dx1_out = d->w1 ? dx1 : d->dfeat;
+    // unary1's LeakyReLU backward rides on the store of K4 / K4G when no bias gradient has to be summed from dz1
+    const float* gate1 = (d->w1 && !d->db1 && ws_block_gates) ? d->x1 : nullptr;
     if (d->grid_blob) {
         WS_REQUIRE(d->key_last && d->grid_overflow && nq == ns, "grid backward needs key_last / overflow and a self-query layer");
-        WS_TRY(ws_kpconv_gather_bwd_x_grid(d->s_pts, ns, d->grid_blob, d->grid_nb, d->grid_cells, d->key_last, d->grid_radius, dwf,
-                                           d->conv_in, d->kernel_points, d->k, nullptr, nullptr, d->extent, WS_INFLUENCE_LINEAR,
-                                           WS_AGGREGATION_SUM, d->order_s, dx1_out, d->grid_overflow, st));
+        WS_TRY(ws_kpconv_gather_bwd_x_grid_gated(d->s_pts, ns, d->grid_blob, d->grid_nb, d->grid_cells, d->key_last, d->grid_radius, dwf,
+                                                 d->conv_in, d->kernel_points, d->k, nullptr, nullptr, d->extent, WS_INFLUENCE_LINEAR,
+                                                 WS_AGGREGATION_SUM, d->order_s, gate1, d->slope, dx1_out, d->grid_overflow, st));
     } else {
         WS_REQUIRE(d->t_offsets && d->t_pairs, "KPConv backward needs the search grid or the transposed table");
-        WS_TRY(ws_kpconv_gather_bwd_x(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, d->t_offsets, d->t_pairs, dwf, d->conv_in,
-                                      d->kernel_points, d->k, nullptr, nullptr, d->extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM,
-                                      d->order_s, dx1_out, st));
+        WS_TRY(ws_kpconv_gather_bwd_x_gated(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, d->t_offsets, d->t_pairs, dwf, d->conv_in,
+                                            d->kernel_points, d->k, nullptr, nullptr, d->extent, WS_INFLUENCE_LINEAR,
+                                            WS_AGGREGATION_SUM, d->order_s, gate1, d->slope, dx1_out, st));
     }
     if (d->w1) {
-        WS_TRY(ws_act_bwd_colsum(dx1, ns, d->conv_in, d->conv_in, d->x1, d->conv_in, d->slope, dx1, d->conv_in, d->db1, tmp, st));
+        if (!gate1)
+            WS_TRY(ws_act_bwd_colsum(dx1, ns, d->conv_in, d->conv_in, d->x1, d->conv_in, d->slope, dx1, d->conv_in, d->db1, tmp, st));
         WS_TRY(ws_gemm_xty(dx1, ns, d->conv_in, d->conv_in, d->feat, d->in_dim, d->in_dim, d->dw1, tmp, st));
         if (d->dfeat)
             WS_TRY(ws_gemm_xb_epilogue_strided(dx1, ns, d->conv_in, d->conv_in, d->w1, d->in_dim, 1, d->in_dim, nullptr, sc_res, d->in_dim,

@@ -25,6 +25,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128;   // rows of X per workgroup (32 per wave)
 constexpr int BK = 32;    // k depth per LDS tile
 
+// Optional multiplicative gates of the GEMM epilogues (applied after bias / residual / activation):
+//   y    rows [m, n] (pitch ld) of ANOTHER layer's activated output: v *= LeakyReLU'(y) = (y > 0 ? 1 : slope) -- the
+//        activation backward of the layer that consumes this product as its gradient (dX = dY W^T gated by that layer's y);
+//   mask rows [m, n] of bytes (pitch ldm): v = mask ? v * mscale : 0 -- dropout, forward (on the activated output) and
+//        backward (on the gradient) alike.
+struct XbGate {
+    const float* y; int64_t ld; float slope;
+    const uint8_t* mask; int64_t ldm; float mscale;
+};
+__device__ __forceinline__ void xb_gate4(float4& v, const XbGate& g, int64_t row, int col)
+{
+    if (g.y) {
+        const float4 q = *reinterpret_cast<const float4*>(g.y + row * g.ld + col);
+        v.x *= q.x > 0.0f ? 1.0f : g.slope; v.y *= q.y > 0.0f ? 1.0f : g.slope;
+        v.z *= q.z > 0.0f ? 1.0f : g.slope; v.w *= q.w > 0.0f ? 1.0f : g.slope;
+    }
+    if (g.mask) {
+        const unsigned mk = *reinterpret_cast<const unsigned*>(g.mask + row * g.ldm + col);
+        v.x = (mk & 0xffu) ? v.x * g.mscale : 0.0f;       v.y = (mk & 0xff00u) ? v.y * g.mscale : 0.0f;
+        v.z = (mk & 0xff0000u) ? v.z * g.mscale : 0.0f;   v.w = (mk & 0xff000000u) ? v.w * g.mscale : 0.0f;
+    }
+}
+__device__ __forceinline__ float xb_gate1(float v, const XbGate& g, int64_t row, int col)
+{
+    if (g.y) v *= g.y[row * g.ld + col] > 0.0f ? 1.0f : g.slope;
+    if (g.mask) v = g.mask[row * g.ldm + col] ? v * g.mscale : 0.0f;
+    return v;
+}
+
 __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ p, int64_t row, int64_t nrows, int col, int ncols,
                                             int64_t ld, bool vec)
 {
@@ -52,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ 
                                                        const float* __restrict__ b, int n, int64_t ldb,
                                                        float* __restrict__ y, int64_t ldy, int vecx, int vecb,
                                                        const float* __restrict__ bias, const float* __restrict__ residual,
-                                                       int64_t ldr, int act, float slope)
+                                                       int64_t ldr, int act, float slope, const XbGate gate)
 {
     constexpr int BN = 32 * NT;
     __shared__ float Xs[BM][BKX + 1];
@@ -127,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ 
                 float v = acc[i][r] + bv;
                 if (residual) v += residual[row * ldr + col];
                 if (act) v = v > 0.0f ? v : v * slope;
-                y[row * ldy + col] = v;
+                y[row * ldy + col] = xb_gate1(v, gate, row, col);
             }
         }
     }
@@ -143,7 +172,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
 __device__ __forceinline__ void xb_rows_epilogue(const f32x16 (&acc)[NT], int64_t row, int64_t m, int n0, int n, int h,
                                                  float* __restrict__ y, int64_t ldy, const float* __restrict__ bias,
-                                                 const float* __restrict__ residual, int64_t ldr, int act, float slope)
+                                                 const float* __restrict__ residual, int64_t ldr, int act, float slope,
+                                                 const XbGate& gate)
 {
     const bool live = row < m;
     const int64_t rr = live ? row : m - 1;
@@ -181,6 +211,10 @@ __device__ __forceinline__ void xb_rows_epilogue(const f32x16 (&acc)[NT], int64_
                 v[g].w = v[g].w > 0.0f ? v[g].w : v[g].w * slope;
             }
         }
+        if (gate.y || gate.mask) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xb_gate4(v[g], gate, rr, col[g] < n ? col[g] : n - 4);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             if (live && col[g] < n) *reinterpret_cast<float4*>(yrow + col[g]) = v[g];
@@ -206,7 +240,7 @@ template <int NT, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_xb2_kernel(
     const float* __restrict__ x, int64_t m, int k, int64_t ldx, const float* __restrict__ b, int n, int ldb, int bcs,
     float* __restrict__ y, int64_t ldy, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldr,
-    int act, float slope, int csplit, float* __restrict__ partial)
+    int act, float slope, int csplit, float* __restrict__ partial, const XbGate gate)
 {
     // split-K (gridDim.z > 1; few rows, deep k): workgroup z contracts chunks [z*csplit, (z+1)*csplit) and
     // writes its raw sums to partial[z][m][n]; splitk_epilogue_kernel adds them in a fixed order
@@ -328,15 +362,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     }
     if (partial)
         xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, partial + (int64_t)blockIdx.z * m * n, n, nullptr, nullptr, 0,
-                             0, 0.0f);
+                             0, 0.0f, XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f});
     else
-        xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope);
+        xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope, gate);
 }
 
 // y = act(sum_z partial[z] + bias + residual): the epilogue of a split-K gemm_xb2 (fixed order over z)
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ partial, int splits, int64_t m, int n,
                                                                float* __restrict__ y, int64_t ldy, const float* __restrict__ bias,
-                                                               const float* __restrict__ residual, int64_t ldr, int act, float slope)
+                                                               const float* __restrict__ residual, int64_t ldr, int act, float slope,
+                                                               const XbGate gate)
 {
     const int n4 = n >> 2;
     const int64_t total = m * n4;
@@ -357,6 +392,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
             v.x = v.x > 0.0f ? v.x : v.x * slope; v.y = v.y > 0.0f ? v.y : v.y * slope;
             v.z = v.z > 0.0f ? v.z : v.z * slope; v.w = v.w > 0.0f ? v.w : v.w * slope;
         }
+        xb_gate4(v, gate, r, c);
         *reinterpret_cast<float4*>(y + r * ldy + c) = v;
     }
 }
@@ -841,7 +877,7 @@ int64_t ws_gemm_xb_scratch_bytes(int64_t m, int32_t k, int32_t n)
 static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                         const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
                         float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream,
-                        int64_t brs = -1, int64_t bcs = 1)
+                        int64_t brs = -1, int64_t bcs = 1, XbGate gate = XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f})
 {
     if (brs < 0) brs = n;                       // row-major [K,N]
     WS_REQUIRE(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
@@ -857,7 +893,8 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
     if (ws_gemm_variant == 2 && vecx && k % 32 == 0 && n % 4 == 0 && al16(y) && ldy % 4 == 0 &&
         (!residual || (al16(residual) && ldr % 4 == 0)) && (!bias || al16(bias)) &&
         (int64_t)(k - 1) * brs + (int64_t)(n - 1) * bcs < (1ll << 29) && 128 * ldx < (1ll << 29) && al16(b) &&
-        (bcs == 1 ? true : (brs == 1 && bcs % 4 == 0))) {
+        (bcs == 1 ? true : (brs == 1 && bcs % 4 == 0)) &&
+        (!gate.y || (al16(gate.y) && gate.ld % 4 == 0)) && (!gate.mask || ((reinterpret_cast<uintptr_t>(gate.mask) & 3u) == 0 && gate.ldm % 4 == 0))) {
 #define WS_XB2(NTV, WNV)                                                                                        \
     do {                                                                                                        \
         const unsigned gx2 = (unsigned)ws_ceil_div(m, 32 * (4 / WNV)), gy2 = (unsigned)ws_ceil_div(n, 32 * NTV * WNV); \
@@ -874,10 +911,10 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
         splits = (int)ws_ceil_div(nch, csplit);                                                                 \
         float* part = splits > 1 ? (float*)scratch : nullptr;                                                   \
         gemm_xb2_kernel<NTV, WNV><<<dim3(gx2, gy2, (unsigned)splits), 256, 0, st>>>(x, m, k, ldx, b, n, (int)brs, (int)bcs, y, ldy, bias, residual, \
-                                                                                    ldr, act, slope, csplit, part);         \
+                                                                                    ldr, act, slope, csplit, part, gate);   \
         if (splits > 1)                                                                                         \
             splitk_epilogue_kernel<<<ws_grid(m * (n / 4), 256), 256, 0, st>>>(part, splits, m, n, y, ldy, bias, residual, ldr, \
-                                                                              act, slope);                      \
+                                                                              act, slope, gate);                \
     } while (0)
         const int64_t tiles = ws_ceil_div(m, 32);
         int wn = tiles >= 2048 ? 1 : 2;
@@ -899,19 +936,19 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
                                      "(k=%d n=%d): pass a row-major [K,N] copy for this shape", k, n);
     if (n <= 32) {
         gemm_xb_kernel<1, 32><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
-                                                                 act, slope);
+                                                                 act, slope, gate);
     } else if (n <= 64) {
         gemm_xb_kernel<2, 32><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
-                                                                 act, slope);
+                                                                 act, slope, gate);
     } else {
         // measured (tools/gemm_bench.py, M = 400k): shallow K is latency bound and prefers the 64-column
         // tile (more waves per SIMD, L2 serves the X re-read); deep K prefers the 128-column tile (X reuse)
         if (k < 128)
             gemm_xb_kernel<2, 32><<<dim3((unsigned)gx, (unsigned)ws_ceil_div(n, 64)), 256, 0, st>>>(
-                x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr, act, slope);
+                x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr, act, slope, gate);
         else
             gemm_xb_kernel<4, 32><<<dim3((unsigned)gx, (unsigned)ws_ceil_div(n, 128)), 256, 0, st>>>(
-                x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr, act, slope);
+                x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr, act, slope, gate);
     }
     WS_LAUNCH_CHECK();
     return WS_OK;
@@ -973,6 +1010,18 @@ int ws_gemm_xb_epilogue_strided(const float* x, int64_t m, int32_t k, int64_t ld
 {
     return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
                         b_row_stride, b_col_stride);
+}
+
+int ws_gemm_xb_gated_strided(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride,
+                             int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
+                             int32_t act, float slope, const float* gate_y, int64_t ldg, float gate_slope, const uint8_t* mask,
+                             int64_t ldm, float mask_scale, float* y, int64_t ldy, void* scratch, int64_t scratch_bytes,
+                             void* stream)
+{
+    WS_REQUIRE(!gate_y || ldg >= n, "gate leading dimension too small");
+    WS_REQUIRE(!mask || ldm >= n, "mask leading dimension too small");
+    return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
+                        b_row_stride, b_col_stride, XbGate{gate_y, ldg, gate_slope, mask, ldm, mask_scale});
 }
 
 int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n, float* y, int64_t ldy,

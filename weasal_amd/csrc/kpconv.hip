@@ -24,6 +24,9 @@ struct GeomParams {
     int deformable;   // 1: apply the in-range filter of blocks.py:301-325
     int ablate;       // diagnostics only (tools/kpconv_lab.py): 1 = no wf store, 2 = every row gather reads row 0,
                       // 4 = coordinates of point `lane` instead of the neighbour's, 8 = no index load
+    const void* gate; // K4 / K4G only: rows [ns, ci] of the activated output y of the layer that produced x; the stored
+    float gate_slope; // gradient is dx * LeakyReLU'(y) (1 where y > 0, gate_slope elsewhere) -- the activation backward
+                      // of the preceding unary block folded into the store.  NULL: plain dx.
 };
 
 // Influence of the K kernel points on one neighbour offset n = s - q.  kp is wave-uniform.
@@ -889,6 +892,19 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
             const int ch = cc0 + 4 * j;
             const bool chok = VEC ? (ch + 3 < ci) : (ch < ci);
             const int chl = chok ? ch : 0;
+            // the gate row (GeomParams::gate) is fetched here, ahead of the walk: at the store its latency has long passed
+            float4 gq = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (g.gate && slot == 0) {
+                const T* gy = reinterpret_cast<const T*>(g.gate) + s * ci + ch;
+                if (VEC) {
+                    if (chok) gq = ld4(gy);
+                } else {
+                    if (ch + 0 < ci) gq.x = ld1(gy + 0);
+                    if (ch + 1 < ci) gq.y = ld1(gy + 1);
+                    if (ch + 2 < ci) gq.z = ld1(gy + 2);
+                    if (ch + 3 < ci) gq.w = ld1(gy + 3);
+                }
+            }
             auto flush = [&](int total) {
                 wave_lds_sync();
                 total = min(total, POOL);
@@ -957,6 +973,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
             }
             if (slot == 0) {
                 T* dst = dx + s * ci + ch;
+                if (g.gate) {
+                    acc.x *= gq.x > 0.0f ? 1.0f : g.gate_slope; acc.y *= gq.y > 0.0f ? 1.0f : g.gate_slope;
+                    acc.z *= gq.z > 0.0f ? 1.0f : g.gate_slope; acc.w *= gq.w > 0.0f ? 1.0f : g.gate_slope;
+                }
                 if (VEC) {
                     if (chok) st4(dst, acc);
                 } else {
@@ -1251,6 +1271,19 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
             const int ch = cc0 + 4 * j;
             const bool chok = VEC ? (ch + 3 < ci) : (ch < ci);
             const int chl = chok ? ch : 0;
+            // the gate row (GeomParams::gate) is fetched here, ahead of the walk: at the store its latency has long passed
+            float4 gq = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (g.gate && slot == 0) {
+                const T* gy = reinterpret_cast<const T*>(g.gate) + s * ci + ch;
+                if (VEC) {
+                    if (chok) gq = ld4(gy);
+                } else {
+                    if (ch + 0 < ci) gq.x = ld1(gy + 0);
+                    if (ch + 1 < ci) gq.y = ld1(gy + 1);
+                    if (ch + 2 < ci) gq.z = ld1(gy + 2);
+                    if (ch + 3 < ci) gq.w = ld1(gy + 3);
+                }
+            }
             auto flush = [&](int total) {
                 wave_lds_sync();
                 total = min(total, POOL);
@@ -1316,6 +1349,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
             }
             if (slot == 0) {
                 T* dst = dx + s * ci + ch;
+                if (g.gate) {
+                    acc.x *= gq.x > 0.0f ? 1.0f : g.gate_slope; acc.y *= gq.y > 0.0f ? 1.0f : g.gate_slope;
+                    acc.z *= gq.z > 0.0f ? 1.0f : g.gate_slope; acc.w *= gq.w > 0.0f ? 1.0f : g.gate_slope;
+                }
                 if (VEC) {
                     if (chok) st4(dst, acc);
                 } else {
@@ -1358,7 +1395,7 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
     if (rc) return rc;
     if (nq == 0) return WS_OK;
     WS_REQUIRE(inds && x && wf && (kernel_points || deformed_kp), "NULL argument");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, nullptr, 0.0f};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(nq, 4);
     WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
@@ -1445,7 +1482,8 @@ int gather_bwd_x_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_
                       const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
                       const T* dwf, int32_t ci, const float* kernel_points, int32_t k,
                       const float* deformed_kp, const float* modulations, float extent,
-                      int32_t influence, int32_t aggregation, const int32_t* order, T* dx, void* stream)
+                      int32_t influence, int32_t aggregation, const int32_t* order, T* dx, void* stream,
+                      const T* gate = nullptr, float gate_slope = 0.0f)
 {
     constexpr bool F32 = sizeof(T) == 4;
     (void)inds;
@@ -1455,7 +1493,7 @@ int gather_bwd_x_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_
     WS_REQUIRE(t_offsets && t_pairs && dwf && dx && (kernel_points || deformed_kp), "NULL argument");
     WS_REQUIRE(nq * (int64_t)h < (1ll << 31), "nq*h exceeds int32");
     WS_REQUIRE(nq * (int64_t)k * ci < (1ll << 31), "nq*k*ci exceeds the 32-bit row offsets of the gather");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, gate, gate_slope};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
@@ -1496,7 +1534,7 @@ int gather_bwd_geom_impl(const float* q_pts, int64_t nq, const float* s_pts, int
     if (rc) return rc;
     if (nq == 0) return WS_OK;
     WS_REQUIRE(inds && x && dwf && deformed_kp && d_deformed_kp, "NULL argument");
-    GeomParams g{extent, influence, aggregation, 1, 0};
+    GeomParams g{extent, influence, aggregation, 1, 0, nullptr, 0.0f};
     hipStream_t st = (hipStream_t)stream;
     kpconv_gather_bwd_geom_kernel<15, T><<<ws_grid(nq, 4), 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf,
                                                                           deformed_kp, modulations, d_min_d2, g,
@@ -1511,7 +1549,7 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
                            const uint64_t* key_last, float radius, const T* dwf, int32_t ci,
                            const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
                            float extent, int32_t influence, int32_t aggregation, const int32_t* order, T* dx,
-                           int32_t* overflow, void* stream)
+                           int32_t* overflow, void* stream, const T* gate = nullptr, float gate_slope = 0.0f)
 {
     constexpr bool F32 = sizeof(T) == 4;
     int rc = check_common(s_pts, ns, s_pts, ns, 1, ci, k, extent, influence, aggregation);
@@ -1520,7 +1558,7 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
     WS_REQUIRE(grid_blob && key_last && dwf && dx && overflow && (kernel_points || deformed_kp), "NULL argument");
     WS_REQUIRE(nb >= 1 && cells >= 1, "bad grid nb=%d cells=%lld", nb, (long long)cells);
     WS_REQUIRE(ns * (int64_t)k * ci < (1ll << 31), "ns*k*ci exceeds the 32-bit row offsets of the gather");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, gate, gate_slope};
     hipStream_t st = (hipStream_t)stream;
     const char* base = (const char*)grid_blob;
     const CloudGrid* grids = (const CloudGrid*)base;
@@ -1647,6 +1685,30 @@ int ws_kpconv_gather_bwd_x_grid_bf16(const float* s_pts, int64_t ns, const void*
     return gather_bwd_x_grid_impl<bf16_t>(s_pts, ns, grid_blob, nb, cells, key_last, radius, reinterpret_cast<const bf16_t*>(dwf), ci,
                                           kernel_points, k, deformed_kp, modulations, extent, influence, aggregation, order,
                                           reinterpret_cast<bf16_t*>(dx), overflow, stream);
+}
+
+// K4 / K4G with the activation backward of the preceding unary block folded into the store: dx * LeakyReLU'(gate_y)
+// (gate_y [ns, ci] = that block's activated output, i.e. this layer's input x).  gate_y NULL = the plain entries above.
+int ws_kpconv_gather_bwd_x_gated(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
+                                 const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
+                                 const float* dwf, int32_t ci, const float* kernel_points, int32_t k,
+                                 const float* deformed_kp, const float* modulations, float extent,
+                                 int32_t influence, int32_t aggregation, const int32_t* order, const float* gate_y,
+                                 float gate_slope, float* dx, void* stream)
+{
+    return gather_bwd_x_impl<float>(q_pts, nq, s_pts, ns, inds, h, t_offsets, t_pairs, dwf, ci, kernel_points, k, deformed_kp,
+                                    modulations, extent, influence, aggregation, order, dx, stream, gate_y, gate_slope);
+}
+
+int ws_kpconv_gather_bwd_x_grid_gated(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                      const uint64_t* key_last, float radius, const float* dwf, int32_t ci,
+                                      const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
+                                      float extent, int32_t influence, int32_t aggregation, const int32_t* order,
+                                      const float* gate_y, float gate_slope, float* dx, int32_t* overflow, void* stream)
+{
+    return gather_bwd_x_grid_impl<float>(s_pts, ns, grid_blob, nb, cells, key_last, radius, dwf, ci, kernel_points, k, deformed_kp,
+                                         modulations, extent, influence, aggregation, order, dx, overflow, stream, gate_y,
+                                         gate_slope);
 }
 
 }  // extern "C"

@@ -53,8 +53,16 @@ class UpUnaryDesc(C.Structure):
                 ("yc", _vp), ("out", _vp), ("dout", _vp), ("dxc", _vp), ("dskip", _vp), ("dw", _vp), ("db", _vp)]
 
 
+_GATES_SET = False
+
+
 def _bind():
-    return _lib.lib()          # signatures: _lib.SIGNATURES (descriptors travel as void* = ctypes.byref(struct))
+    global _GATES_SET
+    lib = _lib.lib()           # signatures: _lib.SIGNATURES (descriptors travel as void* = ctypes.byref(struct))
+    if not _GATES_SET:         # diagnostics: WEASAL_BLOCK_GATES=0 = activation backward as separate passes
+        C.c_int.in_dll(lib, "ws_block_gates").value = 0 if os.environ.get("WEASAL_BLOCK_GATES", "1") == "0" else 1
+        _GATES_SET = True
+    return lib
 
 
 def timer_records():
