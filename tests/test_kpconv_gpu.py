@@ -303,3 +303,26 @@ def test_gated_gather_backward_is_the_plain_one_times_the_activation_derivative(
                                                 ptr(grid.overflow), current_stream()))
     assert torch.equal(gated_g, plain_g * torch.where(gate > 0, 1.0, 0.1).to(plain_g.dtype))
     assert int(grid.overflow.item()) == 0
+
+
+@pytest.mark.parametrize("m,k,n", [(100000, 128, 128), (10257, 1920, 128), (380, 7680, 512), (5000, 64, 32)])
+def test_split_bf16_products_are_fp32_accurate(gpu, m, k, n):
+    """the opt-in gemm_xb3 path (ws_gemm_split = 1: fp32 products as six bf16 MFMA partial products of exact three-way
+    splits) against float64, next to the default f32-input MFMA kernels on the same operands: its error is not larger"""
+    import ctypes
+    from weasal_amd import _lib, ops
+    sw = ctypes.c_int.in_dll(_lib.lib(), "ws_gemm_split")
+    torch.manual_seed(m + k)
+    x = torch.randn(m, k, device=gpu) * torch.exp(torch.randn(m, 1, device=gpu))       # rows of very different scale
+    b = torch.randn(k, n, device=gpu) / k ** 0.5
+    ref = x.double() @ b.double()
+    err = {}
+    try:
+        for mode in (0, 1):
+            sw.value = mode
+            y = ops._gemm_xb(x, b)
+            err[mode] = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+    finally:
+        sw.value = 0
+    assert err[0] < 5e-6 and err[1] < 5e-6
+    assert err[1] <= 1.5 * err[0] + 1e-7

@@ -137,6 +137,10 @@ def lib():
             fn = getattr(handle, name)   # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
+        # diagnostics switches of the library (integer globals), settable from the environment for A/B runs
+        for env, sym in (("WEASAL_GEMM_SPLIT", "ws_gemm_split"),):
+            if env in os.environ:
+                C.c_int.in_dll(handle, sym).value = int(os.environ[env])
         _lib = handle
     return _lib
 

@@ -12,8 +12,36 @@
 
 // diagnostics switch (WEASAL_BLOCK_GATES=0): activation backward as separate passes instead of epilogue / store gates
 extern "C" int ws_block_gates = 1;
+// blocks with fewer query rows than this run their weight-gradient products (dW = X^T dZ: leaves of the backward, nothing
+// on the chain to dX waits for them) on a side stream next to the dX chain -- the deep pyramid levels, whose kernels fill
+// a fraction of the 256 CUs.  0 = off (diagnostics: WEASAL_BLOCK_SIDE_ROWS).
+extern "C" int64_t ws_block_side_rows = 32768;
 
 namespace {
+
+// One side stream and a few events per device, created on first use and kept for the life of the process.
+struct Side {
+    hipStream_t st = nullptr;
+    hipEvent_t fork[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t join = nullptr;
+};
+int side_for_current_device(Side** out)
+{
+    static Side sides[16];
+    int dev = 0;
+    WS_HIP(hipGetDevice(&dev));
+    WS_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+    Side& sd = sides[dev];
+    if (!sd.st) {
+        hipStream_t st;
+        WS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (auto& e : sd.fork) WS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        WS_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+        sd.st = st;
+    }
+    *out = &sd;
+    return WS_OK;
+}
 
 struct Arena {
     char* base;
@@ -177,6 +205,13 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     tmp_bytes = max3(tmp_bytes, ws_gemm_xb_scratch_bytes(nq, d->conv_out, kc), ws_gemm_xb_scratch_bytes(nq, d->out_dim, d->conv_out));
     tmp_bytes = max3(tmp_bytes, ws_gemm_xb_scratch_bytes(nq, d->out_dim, d->in_dim), ws_gemm_xb_scratch_bytes(ns, d->conv_in, d->in_dim));
     void* tmp = ar.take<char>(tmp_bytes > 16 ? tmp_bytes : 16);
+    // the weight-gradient products of a short block run on the side stream with a scratch of their own
+    const bool use_side = ws_block_side_rows > 0 && nq > 0 && ns > 0 && nq < ws_block_side_rows;
+    int64_t side_bytes = ws_gemm_xty_scratch_bytes(nq, kc, d->conv_out);
+    if (d->w2) side_bytes = max3(side_bytes, ws_gemm_xty_scratch_bytes(nq, d->out_dim, d->conv_out),
+                                 d->ws ? ws_gemm_xty_scratch_bytes(nq, d->out_dim, d->in_dim) : 0);
+    if (d->w1) side_bytes = max3(side_bytes, ws_gemm_xty_scratch_bytes(ns, d->conv_in, d->in_dim), 0);
+    void* tmp_w = use_side ? (void*)ar.take<char>(side_bytes > 16 ? side_bytes : 16) : tmp;
     if (!run) return WS_OK;
     WS_REQUIRE(d->dout && d->dwk, "NULL gradient buffer");
     WS_REQUIRE(!d->w1 || d->dw1, "dw1 missing");
@@ -193,16 +228,27 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         return WS_OK;
     }
     bool gated2 = false;
+    // stw: the stream of the dW products; fork(i) makes it wait for what the main stream has produced so far
+    Side* side = nullptr;
+    if (use_side) WS_TRY(side_for_current_device(&side));
+    hipStream_t stw = side ? side->st : st;
+    auto fork = [&](int i) -> int {
+        if (!side) return WS_OK;
+        WS_HIP(hipEventRecord(side->fork[i], st));
+        WS_HIP(hipStreamWaitEvent(stw, side->fork[i], 0));
+        return WS_OK;
+    };
     const float* sc_res = nullptr;          // the shortcut's gradient w.r.t. feat rows [ns,in_dim]
     const float* gin = d->dout;             // gradient entering the convolution's activation
     const float* yconv = d->out;
     if (d->w2) {
         // dz = dout * lrelu'(out), db2 = column sums
         WS_TRY(ws_act_bwd_colsum(d->dout, nq, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, dz, d->out_dim, d->db2, tmp, st));
-        WS_TRY(ws_gemm_xty(dz, nq, d->out_dim, d->out_dim, d->x2, d->conv_out, d->conv_out, d->dw2, tmp, st));
+        WS_TRY(fork(0));
+        WS_TRY(ws_gemm_xty(dz, nq, d->out_dim, d->out_dim, d->x2, d->conv_out, d->conv_out, d->dw2, tmp_w, stw));
         if (d->ws) {
             const float* sc_in = d->strided ? d->pooled : d->feat;
-            WS_TRY(ws_gemm_xty(dz, nq, d->out_dim, d->out_dim, sc_in, d->in_dim, d->in_dim, d->dws, tmp, st));
+            WS_TRY(ws_gemm_xty(dz, nq, d->out_dim, d->out_dim, sc_in, d->in_dim, d->in_dim, d->dws, tmp_w, stw));
         }
         if (want_sc) {
             const float* dsc = dz;          // [nq, in_dim] when there is no projection (in_dim == out_dim)
@@ -231,8 +277,15 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     // dz2 = g * lrelu'(x2), dbk
     if (!gated2)
         WS_TRY(ws_act_bwd_colsum(gin, nq, d->conv_out, d->conv_out, yconv, d->conv_out, d->slope, g2, d->conv_out, d->dbk, tmp, st));
-    WS_TRY(ws_gemm_xty(d->wf, nq, kc, kc, g2, d->conv_out, d->conv_out, d->dwk, tmp, st));
-    if (!need_dx1) return WS_OK;
+    WS_TRY(fork(1));
+    WS_TRY(ws_gemm_xty(d->wf, nq, kc, kc, g2, d->conv_out, d->conv_out, d->dwk, tmp_w, stw));
+    auto join = [&]() -> int {              // the caller's stream continues after the side products
+        if (!side) return WS_OK;
+        WS_HIP(hipEventRecord(side->join, stw));
+        WS_HIP(hipStreamWaitEvent(st, side->join, 0));
+        return WS_OK;
+    };
+    if (!need_dx1) return join();
     // dwf = dz2 @ wk^T
     WS_TRY(linear_fwd(lk, g2, nq, d->conv_out, nullptr, nullptr, 0, 0, 0.0f, dwf, trk, tmp, tmp_bytes, st));
     float* dx1_out = d->w1 ? dx1 : d->dfeat;
@@ -252,7 +305,8 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     if (d->w1) {
         if (!gate1)
             WS_TRY(ws_act_bwd_colsum(dx1, ns, d->conv_in, d->conv_in, d->x1, d->conv_in, d->slope, dx1, d->conv_in, d->db1, tmp, st));
-        WS_TRY(ws_gemm_xty(dx1, ns, d->conv_in, d->conv_in, d->feat, d->in_dim, d->in_dim, d->dw1, tmp, st));
+        WS_TRY(fork(2));
+        WS_TRY(ws_gemm_xty(dx1, ns, d->conv_in, d->conv_in, d->feat, d->in_dim, d->in_dim, d->dw1, tmp_w, stw));
         if (d->dfeat)
             WS_TRY(ws_gemm_xb_epilogue_strided(dx1, ns, d->conv_in, d->conv_in, d->w1, d->in_dim, 1, d->in_dim, nullptr, sc_res, d->in_dim,
                                                0, 0.0f, d->dfeat, d->in_dim, tmp, tmp_bytes, st));
@@ -261,7 +315,7 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         add_rows_kernel<<<ws_grid(n4, 256), 256, 0, st>>>(d->dfeat, sc_res, n4);
         WS_LAUNCH_CHECK();
     }
-    return WS_OK;
+    return join();
 }
 
 // ---- decoder step ------------------------------------------------------------------------------------------------

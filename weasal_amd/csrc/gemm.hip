@@ -367,6 +367,183 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
         xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope, gate);
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_xb3: the same product, fp32 in and out, with every fp32 PRODUCT evaluated on the bf16 MFMA from exact three-way
+// splits of both operands:  x = xh + xm + xl,  w = wh + wm + wl  (bf16 pieces: xh = bf16(x), xm = bf16(x - xh),
+// xl = bf16(x - xh - xm); the subtractions are exact in fp32, so the three pieces carry the full 24-bit mantissa), and
+//     x w  =  xh wh + xh wm + xm wh + xh wl + xl wh + xm wm   +  (xm wl + xl wm + xl wl  <  2^-23 |x w|)
+// six v_mfma_f32_32x32x16_bf16 with fp32 accumulation per 16-deep step instead of eight v_mfma_f32_32x32x2_f32:
+// bf16 products are exact in fp32, the accumulation is the MFMA's fp32 adder either way, and the dropped cross terms
+// are below the rounding of one fp32 product.  What changes is the cost: 6 x 8 passes instead of 8 x 16 for the same
+// 32 x 32 x 16 block (2.7 x the matrix-core throughput), which is what bounds this network in fp32: ~ 0.7 TFLOP per
+// DALES step against the ~ 100 TFLOP/s the f32-input MFMA sustains.  Measured error against float64 is that of the
+// f32-input kernels (tests/test_kpconv_gpu.py::test_split_bf16_products_are_fp32_accurate).
+// Layout: rows on the lanes as in gemm_xb2 (A operand = the small matrix, B operand = X): lane (j, h) of a 32x32x16
+// step holds 8 consecutive k of row j -- two 16-byte loads of X, split in registers; the 32-deep chunk of the small
+// matrix is loaded as fp32 (any strides), split by the staging threads and kept in LDS as three bf16 pieces,
+// k-contiguous rows of 64 + 16 bytes (conflict-free 16-byte fragment reads), double buffered: one barrier per chunk.
+// Preconditions as gemm_xb2 (k % 32 == 0, n % 4 == 0, 16-byte aligned rows); same epilogue, same split-K.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl)
+{
+    ph = ws_pack_bf2(a, b);
+    const float ra = a - ws_bf_lo(ph), rb = b - ws_bf_hi(ph);
+    pm = ws_pack_bf2(ra, rb);
+    pl = ws_pack_bf2(ra - ws_bf_lo(pm), rb - ws_bf_hi(pm));
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_xb3_kernel(
+    const float* __restrict__ x, int64_t m, int k, int64_t ldx, const float* __restrict__ b, int n, int ldb, int bcs,
+    float* __restrict__ y, int64_t ldy, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldr,
+    int act, float slope, int csplit, float* __restrict__ partial, const XbGate gate)
+{
+    constexpr int BN = 32 * NT;
+    constexpr int KC = 32;
+    constexpr int ROWB = 80;                        // bytes per staged row of a piece: 64 + 16 of padding
+    constexpr int PB = BN * 16 / 256;               // (column, k pair) items of the chunk per thread
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3][BN * ROWB];
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t brow0 = (int64_t)blockIdx.x * 128;
+    const int64_t brows = m - brow0 < 128 ? m - brow0 : 128;
+    const int n0 = blockIdx.y * BN;
+    const int cbeg = blockIdx.z * csplit;
+    const int cend = (cbeg + csplit) * KC < k ? cbeg + csplit : k / KC;
+
+    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0,
+                                                        (int)(((int64_t)(k - 1) * ldb + (int64_t)(n - 1) * bcs + 1) * 4), 0x00020000);
+    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + brow0 * ldx), 0,
+                                                        (int)(((brows - 1) * ldx + k) * 4), 0x00020000);
+    // staging items: row-major small matrix -> lanes run along the columns (coalesced rows); transposed in place
+    // (ldb == 1) -> lanes run along k (the 16 pairs of a column are one 128-byte line)
+    const bool wtr = ldb == 1;
+    int woff[PB], wlds[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int g = t + 256 * i;
+        const int c = wtr ? g / 16 : g % BN, kp = wtr ? g % 16 : g / BN;
+        int col = n0 + c;
+        col = col < n ? col : n - 1;                // clamped: valid memory, the column is never stored
+        woff[i] = (2 * kp * ldb + col * bcs) * 4;
+        wlds[i] = c * ROWB + 4 * kp;
+    }
+    float w0[PB], w1[PB];
+    auto load_w = [&](int chunk) {
+        const int so = chunk * KC * ldb * 4;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            w0[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrd, woff[i], so, 0));
+            w1[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wsrd, woff[i], so + ldb * 4, 0));
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            unsigned ph, pm, pl;
+            split3_pair(w0[i], w1[i], ph, pm, pl);
+            *reinterpret_cast<unsigned*>(&Bs[buf][0][wlds[i]]) = ph;
+            *reinterpret_cast<unsigned*>(&Bs[buf][1][wlds[i]]) = pm;
+            *reinterpret_cast<unsigned*>(&Bs[buf][2][wlds[i]]) = pl;
+        }
+    };
+    const int xoff = (int)(((wave * 32 + j) * ldx + 8 * h) * 4);
+    // X runs two chunks ahead of the MFMAs (xn = chunk c + 1, xf = chunk c + 2 in flight): with 2 waves per SIMD the
+    // bytes in flight, not the matrix cores, bound the tall shapes
+    u32x4 xn[4], xf[4];
+    auto load_x = [&](u32x4 (&dst)[4], int chunk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                  // step s = q / 2 (16 k each), half q % 2 of the lane's 8 k
+            dst[q] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, xoff + 64 * (q >> 1) + 16 * (q & 1), chunk * (KC * 4), 0);
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int last = cend - 1;
+    auto split_x = [&](const u32x4 (&raw)[4], u32x4 (&ph)[2], u32x4 (&pm)[2], u32x4 (&pl)[2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const u32x4 a = raw[2 * s2], bq = raw[2 * s2 + 1];
+            unsigned qh[4], qm[4], ql[4];
+            split3_pair(__uint_as_float(a.x), __uint_as_float(a.y), qh[0], qm[0], ql[0]);
+            split3_pair(__uint_as_float(a.z), __uint_as_float(a.w), qh[1], qm[1], ql[1]);
+            split3_pair(__uint_as_float(bq.x), __uint_as_float(bq.y), qh[2], qm[2], ql[2]);
+            split3_pair(__uint_as_float(bq.z), __uint_as_float(bq.w), qh[3], qm[3], ql[3]);
+            ph[s2] = u32x4{qh[0], qh[1], qh[2], qh[3]};
+            pm[s2] = u32x4{qm[0], qm[1], qm[2], qm[3]};
+            pl[s2] = u32x4{ql[0], ql[1], ql[2], ql[3]};
+        }
+    };
+    // software pipeline: while the matrix cores work on chunk c, the vector ALU splits chunk c + 1 (X: registers -> the
+    // pieces of the next iteration; small matrix: registers -> LDS buffer of the next iteration) and chunk c + 2 of X is
+    // in flight.  The bf16 MFMA leaves the issue port free for 7 of its 8 passes: the splits cost no time of their own.
+    u32x4 xh[2], xm[2], xl[2];
+    load_w(cbeg);
+    load_x(xn, cbeg);
+    load_x(xf, cbeg + 1 < last ? cbeg + 1 : last);
+    store_w(0);
+    split_x(xn, xh, xm, xl);
+    __syncthreads();
+    for (int c = cbeg; c < cend; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xn[q] = xf[q];
+        // the small matrix first: its registers are consumed at the end of THIS iteration, and loads return in order --
+        // waiting for them must not also wait for the X chunk requested after them (which is not needed before the next one)
+        load_w(c + 1 < last ? c + 1 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(xf, c + 2 < last ? c + 2 : last);
+        __builtin_amdgcn_sched_barrier(0);
+        const int buf = (c - cbeg) & 1;
+        const unsigned char* bh = &Bs[buf][0][j * ROWB + 16 * h];
+        const unsigned char* bm = &Bs[buf][1][j * ROWB + 16 * h];
+        const unsigned char* bl = &Bs[buf][2][j * ROWB + 16 * h];
+        u32x4 nh[2], nm[2], nl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t fxh = *reinterpret_cast<const bf16x8_t*>(&xh[s2]);
+            const bf16x8_t fxm = *reinterpret_cast<const bf16x8_t*>(&xm[s2]);
+            const bf16x8_t fxl = *reinterpret_cast<const bf16x8_t*>(&xl[s2]);
+            bf16x8_t fwh[NT], fwm[NT], fwl[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                fwh[i] = *reinterpret_cast<const bf16x8_t*>(bh + (32 * i) * ROWB + 32 * s2);
+                fwm[i] = *reinterpret_cast<const bf16x8_t*>(bm + (32 * i) * ROWB + 32 * s2);
+                fwl[i] = *reinterpret_cast<const bf16x8_t*>(bl + (32 * i) * ROWB + 32 * s2);
+            }
+            // smallest terms first; the NT tiles interleave so that no MFMA waits for the previous one's result
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwm[i], fxm, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwh[i], fxl, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwl[i], fxh, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwh[i], fxm, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwm[i], fxh, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwh[i], fxh, acc[i], 0, 0, 0);
+            if (s2 == 0) split_x(xn, nh, nm, nl);     // under the MFMAs of step 0 ...
+            else store_w(buf ^ 1);                    // ... and of step 1 (chunk c + 1; a harmless repeat after the last one)
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { xh[s2] = nh[s2]; xm[s2] = nm[s2]; xl[s2] = nl[s2]; }
+        __syncthreads();
+    }
+    const int64_t row = brow0 + wave * 32 + j;
+    if (partial)
+        xb_rows_epilogue<NT>(acc, row, m, n0, n, h, partial + (int64_t)blockIdx.z * m * n, n, nullptr, nullptr, 0, 0, 0.0f,
+                             XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f});
+    else
+        xb_rows_epilogue<NT>(acc, row, m, n0, n, h, y, ldy, bias, residual, ldr, act, slope, gate);
+}
+
 // y = act(sum_z partial[z] + bias + residual): the epilogue of a split-K gemm_xb2 (fixed order over z)
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ partial, int splits, int64_t m, int n,
                                                                float* __restrict__ y, int64_t ldy, const float* __restrict__ bias,
@@ -866,6 +1043,11 @@ extern "C" {
 // diagnostic switches of tools/gemm_lab.cpp (not part of the drop-in surface of include/weasal_hip.h)
 int ws_gemm_wave_cols = 0;  // forced wave grid of gemm_xb2 (column groups 1 / 2), 0 = automatic
 int ws_gemm_variant = 2;    // 1 = LDS-staged tiles (gemm_xb / gemm_xty), 2 = operands straight from global memory
+int ws_gemm_split = 0;      // 0 = the f32-input MFMA (default: the benchmark's fp32 numbers are measured on it);
+                            // 1 = y = x b with every fp32 product as six bf16 MFMA partial products of exact three-way splits
+                            // (gemm_xb3; WEASAL_GEMM_SPLIT=1): error against float64 not above the f32-input kernels, 15 % less
+                            // time per product at the tall shapes, 2.3 % per DALES training step (12.26 -> 11.98 ms).  Opt-in:
+                            // the gain does not pay for a second arithmetic behind the label "fp32".  2 = the same with 64-column tiles
 
 int64_t ws_gemm_xb_scratch_bytes(int64_t m, int32_t k, int32_t n)
 {
@@ -916,6 +1098,36 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
             splitk_epilogue_kernel<<<ws_grid(m * (n / 4), 256), 256, 0, st>>>(part, splits, m, n, y, ldy, bias, residual, ldr, \
                                                                               act, slope, gate);                \
     } while (0)
+        if (ws_gemm_split) {
+            // fp32 products as six bf16 MFMA partial products (gemm_xb3): 128 rows x 32 NT columns per workgroup
+#define WS_XB3(NTV)                                                                                             \
+    do {                                                                                                        \
+        const unsigned gx3 = (unsigned)ws_ceil_div(m, 128), gy3 = (unsigned)ws_ceil_div(n, 32 * NTV);           \
+        const int nch = k / 32;                                                                                 \
+        int splits = 1;                                                                                         \
+        if (scratch && (int64_t)gx3 * gy3 < 256 && nch >= 8) {                                                  \
+            splits = (int)ws_ceil_div(512, (int64_t)gx3 * gy3);                                                 \
+            if (splits > nch / 4) splits = nch / 4;                                                             \
+            if (splits > 16) splits = 16;                                                                       \
+            if ((int64_t)splits * m * n * 4 > scratch_bytes) splits = (int)(scratch_bytes / (m * n * 4));       \
+            if (splits < 2) splits = 1;                                                                         \
+        }                                                                                                       \
+        const int csplit = (int)ws_ceil_div(nch, splits);                                                       \
+        splits = (int)ws_ceil_div(nch, csplit);                                                                 \
+        float* part = splits > 1 ? (float*)scratch : nullptr;                                                   \
+        gemm_xb3_kernel<NTV><<<dim3(gx3, gy3, (unsigned)splits), 256, 0, st>>>(x, m, k, ldx, b, n, (int)brs, (int)bcs, y, ldy, bias, \
+                                                                               residual, ldr, act, slope, csplit, part, gate); \
+        if (splits > 1)                                                                                         \
+            splitk_epilogue_kernel<<<ws_grid(m * (n / 4), 256), 256, 0, st>>>(part, splits, m, n, y, ldy, bias, residual, ldr, \
+                                                                              act, slope, gate);                \
+    } while (0)
+            if (n <= 32) WS_XB3(1);
+            else if (n <= 64 || ws_gemm_split == 2) WS_XB3(2);
+            else WS_XB3(4);
+#undef WS_XB3
+            WS_LAUNCH_CHECK();
+            return WS_OK;
+        }
         const int64_t tiles = ws_ceil_div(m, 32);
         int wn = tiles >= 2048 ? 1 : 2;
         if (ws_gemm_wave_cols) wn = ws_gemm_wave_cols;
