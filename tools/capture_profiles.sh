@@ -33,3 +33,9 @@ for n,v in sorted(d.items(), key=lambda kv:-sum(kv[1]))[:40]:
 PY
   echo pmc $c done
 done
+bash tools/train_only_trace.sh > $O/train_only_trace.txt 2>&1
+cp gpurun_out/r2_to_agg.csv $O/train_only_kernels.csv
+echo train-only trace done
+python3 tools/split_gemm_lab.py > $O/split_gemm_lab.txt 2>&1
+python3 tools/small_gemm_lab.py > $O/small_gemm_lab.txt 2>&1
+echo gemm labs done
