@@ -12,12 +12,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """-> (rank, local_rank, world).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+def init_from_env(backend=None, force=False):
+    """-> (rank, local_rank, world).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).
+    force: create the process group also for WORLD_SIZE = 1 (tests that run the RCCL branch on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # WEASAL_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)
             backend = os.environ.get("WEASAL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -62,12 +63,16 @@ class GradSync:
     reduced data.  Element-wise the result is the same sum (bit-identical on 2 ranks: tests/test_dp_cpu.py).
 
     The RCCL path (backend "nccl") has not been executed on a multi-GPU node yet (no such node was available to
-    rounds 1-2): only the gloo path is tested."""
+    rounds 1-2): the multi-rank semantics are tested over gloo, the RCCL branch itself on one rank
+    (``single_rank_exchange``, tests/test_dp_gpu.py)."""
 
     TAIL = 2
 
-    def __init__(self, group=None, buckets=1, fill_missing=False):
+    def __init__(self, group=None, buckets=1, fill_missing=False, single_rank_exchange=False):
         self.group = group
+        # single_rank_exchange: run the exchange also in a group of ONE rank (a self all-reduce) -- the only way to execute the
+        # RCCL branch (device buffer, asynchronous handles from the autograd thread, pinned signature copy) on a 1-GPU box
+        self._min_world = 1 if single_rank_exchange else 2
         self.flat = None
         self.params = None
         self.buckets = max(1, int(buckets))
@@ -169,7 +174,7 @@ class GradSync:
         self._launched[b] = True
 
     def _on_grad(self, p):
-        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+        if not (dist.is_initialized() and dist.get_world_size(self.group) >= self._min_world):
             return
         if not self._armed:
             raise RuntimeError("GradSync(buckets>1): backward ran without arm() -- a second backward before the exchange "
@@ -210,7 +215,7 @@ class GradSync:
                                "or use GradSync(fill_missing=True)" % (got, expect))
 
     def __call__(self, net):
-        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+        if not (dist.is_initialized() and dist.get_world_size(self.group) >= self._min_world):
             self._armed = False
             return
         world = dist.get_world_size(self.group)
