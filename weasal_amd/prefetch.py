@@ -38,9 +38,10 @@ class PyramidPrefetcher:
     `workers` background threads, each with its OWN HIP stream and geometry workspaces, build alternate batches and hand
     them over in source order.  One pyramid needs five host round trips (the subsampled sizes of the four levels and the
     row widths of the searches must reach the host before the next level can be shaped), each of which waits for that
-    stream's queued kernels: a single builder is bound by that latency chain (~ 14 ms per DALES batch next to a training
-    stream, although its kernels take 4.7 ms), so the pipeline's rate, not the GPU, paced the training step.  Two builders
-    overlap their chains.  With `seed` each worker draws the grid orientations from its own RandomState(seed + worker);
+    stream's queued kernels: a single builder needs ~ 14 ms per DALES batch next to a training stream (its kernels take
+    3.5-4.7 ms), which is the training step's own time -- measured, one builder keeps up with no loss of step time but
+    with the training thread waiting 0.2-0.3 ms per step for the next batch (14.34-14.45 vs 14.38-14.51 ms with two).
+    Two builders (the default, WEASAL_PREFETCH_WORKERS) overlap their chains and keep a margin.  With `seed` each worker draws the grid orientations from its own RandomState(seed + worker);
     without, the draws come from the global np.random in source order (taken under the source lock when a batch is handed to a
     worker), i.e. the reference's stream exactly, whatever the number of workers."""
 
