@@ -245,6 +245,9 @@ int ws_kpconv_gather_bwd_x_grid(const float* s_pts, int64_t ns, const void* grid
 
 /* K4 / K4G with the activation backward of the preceding unary block folded into the store: dx * LeakyReLU'(gate_y),
  * gate_y [ns, ci] = that block's activated output (this layer's input x); gate_y NULL = the plain entries.
+ * K4G also takes `rows` [ns, rows_h] (NULL = none): the index matrix of the same self-query search.  A support whose own
+ * row was not truncated (key_last[s] = all ones) finds the queries that kept it among its row's entries (the distance is
+ * symmetric bit for bit) instead of walking the 27 cells around it; truncated rows still walk the grid.
  * Replaces the autograd of nn.LeakyReLU between unary1 and KPConv (models/blocks.py:676-683). */
 int ws_kpconv_gather_bwd_x_gated(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
                                  const int64_t* inds, int32_t h, const int32_t* t_offsets, const int32_t* t_pairs,
@@ -256,7 +259,8 @@ int ws_kpconv_gather_bwd_x_grid_gated(const float* s_pts, int64_t ns, const void
                                       const uint64_t* key_last, float radius, const float* dwf, int32_t ci,
                                       const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
                                       float extent, int32_t influence, int32_t aggregation, const int32_t* order,
-                                      const float* gate_y, float gate_slope, float* dx, int32_t* overflow, void* stream);
+                                      const float* gate_y, float gate_slope, const int64_t* rows, int32_t rows_h, float* dx,
+                                      int32_t* overflow, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Grid subsampling -- replaces cpp_wrappers/cpp_subsampling (grid_subsampling.subsample_batch /

@@ -281,9 +281,9 @@ def test_gated_gather_backward_is_the_plain_one_times_the_activation_derivative(
     lens = [6000]
     radius, extent, ci = 0.25, 0.12, 32
     searches = ops.DeferredSearches(gpu)
-    _, _, grid = searches.add(pts, pts, lens, lens, radius, 40, want_grid=True)
+    _, _, grid = searches.add(pts, pts, lens, lens, radius, 10, want_grid=True)      # ~12 neighbours on average: some rows truncated
     inds, = searches.finish()
-    assert 1 < inds.shape[1] <= 40 and searches.last_counts[0] <= 128
+    assert 1 < inds.shape[1] <= 10 and searches.last_counts[0] <= 128
     kp = torch.from_numpy((rng.randn(15, 3) * 0.08).astype(np.float32)).to(gpu)
     dwf = torch.randn(6000, 15 * ci, device=gpu)
     gate = torch.randn(6000, ci, device=gpu)
@@ -299,9 +299,18 @@ def test_gated_gather_backward_is_the_plain_one_times_the_activation_derivative(
     check(lib.ws_kpconv_gather_bwd_x_grid(ptr(pts), 6000, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last), radius, ptr(dwf), ci,
                                           ptr(kp), 15, None, None, extent, 0, 0, None, ptr(plain_g), ptr(grid.overflow), current_stream()))
     check(lib.ws_kpconv_gather_bwd_x_grid_gated(ptr(pts), 6000, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last), radius, ptr(dwf),
-                                                ci, ptr(kp), 15, None, None, extent, 0, 0, None, ptr(gate), 0.1, ptr(gated_g),
+                                                ci, ptr(kp), 15, None, None, extent, 0, 0, None, ptr(gate), 0.1, None, 0, ptr(gated_g),
                                                 ptr(grid.overflow), current_stream()))
     assert torch.equal(gated_g, plain_g * torch.where(gate > 0, 1.0, 0.1).to(plain_g.dtype))
+    # candidates from the supports' own untruncated rows (limit 10 truncates about half of the rows: both paths are live): the same pairs,
+    # summed in another order
+    rows_g = torch.empty(6000, ci, device=gpu)
+    check(lib.ws_kpconv_gather_bwd_x_grid_gated(ptr(pts), 6000, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last), radius, ptr(dwf),
+                                                ci, ptr(kp), 15, None, None, extent, 0, 0, None, None, 0.0, ptr(inds), inds.shape[1],
+                                                ptr(rows_g), ptr(grid.overflow), current_stream()))
+    untruncated = int((grid.key_last == -1).sum())
+    assert 0 < untruncated < 6000
+    assert float((rows_g - plain_g).abs().max()) <= 2e-6 * float(plain_g.abs().max())
     assert int(grid.overflow.item()) == 0
 
 

@@ -103,7 +103,7 @@ SIGNATURES = {
     "ws_kpconv_gather_bwd_x_gated": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32,
                                               _vp, _vp, _f32, _i32, _i32, _vp, _vp, _f32, _vp, _vp]),
     "ws_kpconv_gather_bwd_x_grid_gated": (C.c_int, [_vp, _i64, _vp, _i32, _i64, _vp, C.c_float, _vp, _i32, _vp, _i32, _vp, _vp,
-                                                    C.c_float, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp]),
+                                                    C.c_float, _i32, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _vp]),
     "ws_vote_update": (C.c_int, [_vp, _i64, _i32, _vp, _f32, _vp, _vp, _i64, _f32, _vp]),
     "ws_project_confusion": (C.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
     "ws_potentials_scratch_bytes": (_i64, [_i64]),
@@ -138,7 +138,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         # diagnostics switches of the library (integer globals), settable from the environment for A/B runs
-        for env, sym in (("WEASAL_GEMM_SPLIT", "ws_gemm_split"),):
+        for env, sym in (("WEASAL_GEMM_SPLIT", "ws_gemm_split"), ("WEASAL_K4G_ROWS", "ws_kpconv_grid_rows")):
             if env in os.environ:
                 C.c_int.in_dll(handle, sym).value = int(os.environ[env])
         _lib = handle

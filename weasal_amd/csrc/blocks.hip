@@ -296,7 +296,8 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         WS_REQUIRE(d->key_last && d->grid_overflow && nq == ns, "grid backward needs key_last / overflow and a self-query layer");
         WS_TRY(ws_kpconv_gather_bwd_x_grid_gated(d->s_pts, ns, d->grid_blob, d->grid_nb, d->grid_cells, d->key_last, d->grid_radius, dwf,
                                                  d->conv_in, d->kernel_points, d->k, nullptr, nullptr, d->extent, WS_INFLUENCE_LINEAR,
-                                                 WS_AGGREGATION_SUM, d->order_s, gate1, d->slope, dx1_out, d->grid_overflow, st));
+                                                 WS_AGGREGATION_SUM, d->order_s, gate1, d->slope, d->inds, d->h, dx1_out,
+                                                 d->grid_overflow, st));
     } else {
         WS_REQUIRE(d->t_offsets && d->t_pairs, "KPConv backward needs the search grid or the transposed table");
         WS_TRY(ws_kpconv_gather_bwd_x_gated(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, d->t_offsets, d->t_pairs, dwf, d->conv_in,

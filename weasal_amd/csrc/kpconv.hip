@@ -27,6 +27,10 @@ struct GeomParams {
     const void* gate; // K4 / K4G only: rows [ns, ci] of the activated output y of the layer that produced x; the stored
     float gate_slope; // gradient is dx * LeakyReLU'(y) (1 where y > 0, gate_slope elsewhere) -- the activation backward
                       // of the preceding unary block folded into the store.  NULL: plain dx.
+    const int64_t* rows;  // K4G only: the index matrix [ns, rows_h] of the SAME self-query search the grid belongs to (NULL:
+    int rows_h;           // none).  A support whose own row was not truncated (key_last[s] = "infinity") holds every
+                          // point within the radius in that row -- a superset of the queries that kept s -- so its
+                          // candidates are the row's entries instead of the 27-cell walk.
 };
 
 // Influence of the K kernel points on one neighbour offset n = s - q.  kp is wave-uniform.
@@ -1194,7 +1198,19 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
             slab[(hit && pos < GRID_SLAB) ? pos : GRID_SLAB + lane] = c;      // branch free (dummy slot per lane)
             cnt += __builtin_popcountll(m);
         };
-        if (gr.s_len > 0) {
+        // a support with an untruncated row of its own: every point within the radius is in that row (the distance is
+        // symmetric bit for bit), so the queries that kept s are among its entries -- ~60 candidates instead of the ~700 of
+        // the 27-cell walk.  Wave-uniform branch (s is).
+        const bool from_row = g.rows != nullptr && key_last[s] == ~0ull;
+        if (from_row) {
+            for (int h0 = 0; h0 < g.rows_h; h0 += 64) {
+                const int col = h0 + lane;
+                const int64_t qi = col < g.rows_h ? g.rows[s * g.rows_h + col] : -1;
+                const bool active = qi >= 0 && qi < ns;
+                const int64_t qq = active ? qi : 0;
+                take(make_float4(s_pts[3 * qq + 0], s_pts[3 * qq + 1], s_pts[3 * qq + 2], __int_as_float((int)qq)), active);
+            }
+        } else if (gr.s_len > 0) {
             const int cx = cell_coord(sx, gr.lo[0], gr.inv_cell);
             const int cy = cell_coord(sy, gr.lo[1], gr.inv_cell);
             const int cz = cell_coord(sz, gr.lo[2], gr.inv_cell);
@@ -1378,6 +1394,8 @@ extern "C" int ws_kpconv_ablate;          // diagnostics (GeomParams::ablate); 0
 int ws_kpconv_ablate = 0;
 extern "C" int ws_kpconv_gs;              // diagnostics: > 0 forces the group size of the Ci = 32 matrix-core kernel
 int ws_kpconv_gs = 0;
+extern "C" int ws_kpconv_grid_rows;       // diagnostics: 0 = K4G always walks the cell grid (WEASAL_K4G_ROWS=0)
+int ws_kpconv_grid_rows = 1;
 extern "C" int ws_kpconv_grid_sorted;     // 1: ws_kpconv_gather_bwd_x_grid sums the incoming pairs in index order (the pair order of
 int ws_kpconv_grid_sorted = 0;            //    the transposed table: bit-identical to ws_kpconv_gather_bwd_x); 0: in grid-walk order
 
@@ -1395,7 +1413,7 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
     if (rc) return rc;
     if (nq == 0) return WS_OK;
     WS_REQUIRE(inds && x && wf && (kernel_points || deformed_kp), "NULL argument");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, nullptr, 0.0f};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, nullptr, 0.0f, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(nq, 4);
     WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
@@ -1493,7 +1511,7 @@ int gather_bwd_x_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_
     WS_REQUIRE(t_offsets && t_pairs && dwf && dx && (kernel_points || deformed_kp), "NULL argument");
     WS_REQUIRE(nq * (int64_t)h < (1ll << 31), "nq*h exceeds int32");
     WS_REQUIRE(nq * (int64_t)k * ci < (1ll << 31), "nq*k*ci exceeds the 32-bit row offsets of the gather");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, gate, gate_slope};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, gate, gate_slope, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
@@ -1534,7 +1552,7 @@ int gather_bwd_geom_impl(const float* q_pts, int64_t nq, const float* s_pts, int
     if (rc) return rc;
     if (nq == 0) return WS_OK;
     WS_REQUIRE(inds && x && dwf && deformed_kp && d_deformed_kp, "NULL argument");
-    GeomParams g{extent, influence, aggregation, 1, 0, nullptr, 0.0f};
+    GeomParams g{extent, influence, aggregation, 1, 0, nullptr, 0.0f, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     kpconv_gather_bwd_geom_kernel<15, T><<<ws_grid(nq, 4), 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf,
                                                                           deformed_kp, modulations, d_min_d2, g,
@@ -1549,7 +1567,8 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
                            const uint64_t* key_last, float radius, const T* dwf, int32_t ci,
                            const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
                            float extent, int32_t influence, int32_t aggregation, const int32_t* order, T* dx,
-                           int32_t* overflow, void* stream, const T* gate = nullptr, float gate_slope = 0.0f)
+                           int32_t* overflow, void* stream, const T* gate = nullptr, float gate_slope = 0.0f,
+                           const int64_t* rows = nullptr, int32_t rows_h = 0)
 {
     constexpr bool F32 = sizeof(T) == 4;
     int rc = check_common(s_pts, ns, s_pts, ns, 1, ci, k, extent, influence, aggregation);
@@ -1558,7 +1577,9 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
     WS_REQUIRE(grid_blob && key_last && dwf && dx && overflow && (kernel_points || deformed_kp), "NULL argument");
     WS_REQUIRE(nb >= 1 && cells >= 1, "bad grid nb=%d cells=%lld", nb, (long long)cells);
     WS_REQUIRE(ns * (int64_t)k * ci < (1ll << 31), "ns*k*ci exceeds the 32-bit row offsets of the gather");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, gate, gate_slope};
+    WS_REQUIRE(!rows || rows_h >= 1, "index rows given without their width");
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, gate, gate_slope,
+                 ws_kpconv_grid_rows ? rows : nullptr, rows_h};
     hipStream_t st = (hipStream_t)stream;
     const char* base = (const char*)grid_blob;
     const CloudGrid* grids = (const CloudGrid*)base;
@@ -1704,11 +1725,12 @@ int ws_kpconv_gather_bwd_x_grid_gated(const float* s_pts, int64_t ns, const void
                                       const uint64_t* key_last, float radius, const float* dwf, int32_t ci,
                                       const float* kernel_points, int32_t k, const float* deformed_kp, const float* modulations,
                                       float extent, int32_t influence, int32_t aggregation, const int32_t* order,
-                                      const float* gate_y, float gate_slope, float* dx, int32_t* overflow, void* stream)
+                                      const float* gate_y, float gate_slope, const int64_t* rows, int32_t rows_h, float* dx,
+                                      int32_t* overflow, void* stream)
 {
     return gather_bwd_x_grid_impl<float>(s_pts, ns, grid_blob, nb, cells, key_last, radius, dwf, ci, kernel_points, k, deformed_kp,
                                          modulations, extent, influence, aggregation, order, dx, overflow, stream, gate_y,
-                                         gate_slope);
+                                         gate_slope, rows, rows_h);
 }
 
 }  // extern "C"
