@@ -310,9 +310,10 @@ def main():
         # ---- roofline of the fused KPConv gather kernel (K3) on the largest layer: HIP events on the launch stream,
         #      recorded inside the block calls (ws_timer_*) or around the operator launch (ops timer)
         summ = timer.summary()
-        recs = {}
-        for nq_, h_, ci_, ms_ in fused.timer_records():
+        recs, layer_ms = {}, {}
+        for nq_, h_, ci_, ms_, ml_ in fused.timer_records(layer=True):
             recs.setdefault(("kpconv_gather_fwd", nq_, h_, ci_), []).append(ms_)
+            layer_ms.setdefault(("kpconv_gather_fwd", nq_, h_, ci_), []).append(ml_)
         for k_, v_ in recs.items():
             if k_ in summ:
                 tot = summ[k_][0] * summ[k_][1] + sum(v_)
@@ -347,6 +348,13 @@ def main():
                                "achieved_hbm_measured": (traffic / (ms_k * 1e-3) / 1e9) if traffic else None,
                                "u_fwd_bytes": u_fwd(nq, nq, h, ci, ci, es),
                                "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": ms_k, "launches_timed": count}
+            if key in layer_ms:
+                # the whole layer B_fwd describes (gather + the contraction wf x W that follows it: two launches, `wf` makes
+                # a round trip through HBM between them), by HIP events from the start of the first to the end of the second
+                ml = float(np.mean(layer_ms[key]))
+                res["roofline"]["layer"] = {"what": "K3 gather + contraction [N,15Ci]x[15Ci,Co] of the same layer (two launches)",
+                                            "avg_ms": ml, "achieved": bytes_alg / (ml * 1e-3) / 1e9,
+                                            "frac": bytes_alg / (ml * 1e-3) / 1e9 / HBM_PEAK_GBS}
             # per-launch means of the KPConv gather kernels, grouped by layer (N varies by a few points from
             # batch to batch with the random grid orientation: rounded to two significant digits)
             agg = {}

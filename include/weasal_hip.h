@@ -483,6 +483,9 @@ int ws_gemm_xb_gated_strided(const float* x, int64_t m, int32_t k, int64_t ldx, 
 int ws_timer_reset(void);
 int ws_timer_count(void);
 int ws_timer_read(int32_t i, int64_t* nq, int32_t* h, int32_t* ci, float* ms);
+/* the same record, from the start of the K3 launch to the end of the contraction that follows it: the whole KPConv layer
+ * (models/blocks.py:278-374), the unit SURVEY section 8d's B_fwd describes */
+int ws_timer_read_layer(int32_t i, float* ms);
 
 
 /* ------------------------------------------------------------------------------------------

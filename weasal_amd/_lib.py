@@ -115,6 +115,7 @@ SIGNATURES = {
     "ws_timer_reset": (C.c_int, []),
     "ws_timer_count": (C.c_int, []),
     "ws_timer_read": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
+    "ws_timer_read_layer": (C.c_int, [_i32, _vp]),
 }
 
 _lib = None

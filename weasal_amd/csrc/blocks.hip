@@ -104,7 +104,7 @@ int linear_fwd(const Lin& l, const float* x, int64_t m, int64_t ldx, const float
     } while (0)
 
 // ---- launch timer (bench.py: HIP events around the K3 launch, on the launch stream) --------------------------
-struct TimerRec { hipEvent_t a, b; int64_t nq; int32_t h, ci; };
+struct TimerRec { hipEvent_t a, b, c; int64_t nq; int32_t h, ci; };      // a .. b: the K3 launch, a .. c: K3 + the contraction
 std::vector<TimerRec>& timer_recs() { static std::vector<TimerRec> v; return v; }
 
 int check_kpblock(const ws_kpblock* d)
@@ -160,13 +160,15 @@ int kpblock_fwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     }
     WS_TRY(ws_kpconv_gather_fwd(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, x1, d->conv_in, d->kernel_points, d->k, nullptr, nullptr,
                                 d->extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, d->order_q, d->wf, nullptr, st));
-    if (d->timed) {
-        WS_HIP(hipEventRecord(rec.b, st));
-        timer_recs().push_back(rec);
-    }
+    if (d->timed) WS_HIP(hipEventRecord(rec.b, st));
     float* x2 = d->w2 ? d->x2 : d->out;
     WS_TRY(ws_gemm_xb_epilogue_strided(d->wf, nq, d->k * d->conv_in, (int64_t)d->k * d->conv_in, d->wk, d->conv_out, 1, d->conv_out,
                                        d->bk, nullptr, 0, 1, d->slope, x2, d->conv_out, tmp, tmp_bytes, st));
+    if (d->timed) {
+        WS_HIP(hipEventCreate(&rec.c));
+        WS_HIP(hipEventRecord(rec.c, st));
+        timer_recs().push_back(rec);
+    }
     if (!d->w2) return WS_OK;
     const float* sc_in = d->feat;
     if (d->strided) {
@@ -474,6 +476,7 @@ int ws_timer_reset(void)
     for (auto& r : timer_recs()) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.c);
     }
     timer_recs().clear();
     return WS_OK;
@@ -488,6 +491,15 @@ int ws_timer_read(int32_t i, int64_t* nq, int32_t* h, int32_t* ci, float* ms)
     WS_HIP(hipEventSynchronize(r.b));
     WS_HIP(hipEventElapsedTime(ms, r.a, r.b));
     *nq = r.nq; *h = r.h; *ci = r.ci;
+    return WS_OK;
+}
+
+int ws_timer_read_layer(int32_t i, float* ms)
+{
+    WS_REQUIRE(i >= 0 && i < (int)timer_recs().size() && ms, "bad timer record index %d", i);
+    const TimerRec& r = timer_recs()[i];
+    WS_HIP(hipEventSynchronize(r.c));
+    WS_HIP(hipEventElapsedTime(ms, r.a, r.c));
     return WS_OK;
 }
 

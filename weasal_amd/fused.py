@@ -67,14 +67,19 @@ def _bind():
     return lib
 
 
-def timer_records():
-    """[(nq, h, ci, ms)] of the K3 launches timed inside the block calls since the last reset (synchronises)"""
+def timer_records(layer=False):
+    """[(nq, h, ci, ms)] of the K3 launches timed inside the block calls since the last reset (synchronises);
+    layer=True: [(nq, h, ci, ms, ms_layer)] with the time from the start of K3 to the end of the contraction"""
     lib = _bind()
     out = []
-    nq, h, ci, ms = _i64(), _i32(), _i32(), _f32()
+    nq, h, ci, ms, ml = _i64(), _i32(), _i32(), _f32(), _f32()
     for i in range(lib.ws_timer_count()):
         check(lib.ws_timer_read(i, C.byref(nq), C.byref(h), C.byref(ci), C.byref(ms)))
-        out.append((nq.value, h.value, ci.value, ms.value))
+        if layer:
+            check(lib.ws_timer_read_layer(i, C.byref(ml)))
+            out.append((nq.value, h.value, ci.value, ms.value, ml.value))
+        else:
+            out.append((nq.value, h.value, ci.value, ms.value))
     return out
 
 
