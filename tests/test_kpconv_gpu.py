@@ -335,3 +335,16 @@ def test_split_bf16_products_are_fp32_accurate(gpu, m, k, n):
         sw.value = 0
     assert err[0] < 5e-6 and err[1] < 5e-6
     assert err[1] <= 1.5 * err[0] + 1e-7
+    # dW = x^T dy on the same path
+    dy = torch.randn(m, n, device=gpu) * torch.exp(torch.randn(m, 1, device=gpu))
+    xs = torch.randn(m, min(k, 512), device=gpu)
+    ref_w = xs.double().t() @ dy.double()
+    errw = {}
+    try:
+        for mode in (0, 1):
+            sw.value = mode
+            o = ops._gemm_xty(_lib.lib(), xs, dy)
+            errw[mode] = ((o.double() - ref_w).abs().max() / ref_w.abs().max()).item()
+    finally:
+        sw.value = 0
+    assert errw[0] < 5e-6 and errw[1] < 5e-6 and errw[1] <= 1.5 * errw[0] + 2e-7

@@ -40,3 +40,22 @@ for m, k, n in shapes:
     print("M=%6d K=%5d N=%5d | f32 MFMA %7.1f us err %.1e | split NT4 %7.1f us (%5.1f TF/s) err %.1e | split NT2 %7.1f us err %.1e"
           % (m, k, n, res[0][0], res[0][1], res[1][0], fl / res[1][0] / 1e6, res[1][1], res[2][0], res[2][1]), flush=True)
 print("totals: f32 MFMA %.0f us, split %.0f us, split NT2 %.0f us" % tuple(tot))
+
+print("dW = x^T dy:")
+tot = [0.0, 0.0]
+for m, k, n in [(400000, 128, 128), (400000, 480, 32), (400000, 32, 128), (400000, 128, 32), (71070, 256, 256), (71070, 960, 64), (10257, 1920, 128),
+                (10257, 512, 512), (1526, 3840, 256), (380, 7680, 512), (380, 2048, 512)]:
+    torch.manual_seed(2)
+    x = torch.randn(m, k, device=dev)
+    dy = torch.randn(m, n, device=dev) * torch.exp(torch.randn(m, 1, device=dev))
+    ref = x.double().t() @ dy.double()
+    res = []
+    for mode in (0, 1):
+        sw.value = mode
+        o = ops._gemm_xty(lib, x, dy)
+        err = ((o.double() - ref).abs().max() / ref.abs().max()).item()
+        t = timeit(lambda: ops._gemm_xty(lib, x, dy))
+        res.append((t, err)); tot[mode] += t
+    print("M=%6d K=%5d N=%5d | f32 MFMA %7.1f us err %.1e | split %7.1f us err %.1e" % (m, k, n, res[0][0], res[0][1], res[1][0], res[1][1]), flush=True)
+sw.value = 0
+print("totals: f32 MFMA %.0f us, split %.0f us" % tuple(tot))

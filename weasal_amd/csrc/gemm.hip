@@ -726,7 +726,10 @@ __device__ __forceinline__ void xty_load_cols(__amdgpu_buffer_rsrc_t srd, int of
     }
 }
 
-template <int KT, int NT, int WK, int WN, typename TI = float>
+// SPLIT (float operands only; opt-in, ws_gemm_split): the 16 rows of a block are one v_mfma_f32_32x32x16_bf16 step per
+// bf16 piece pair -- both operands split three ways in registers as in gemm_xb3 (lane group h holds rows h, 2 + h, ..,
+// 14 + h of the block as its 8 k; A and B use the same assignment, so the contraction is the same set of products)
+template <int KT, int NT, int WK, int WN, typename TI = float, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_xty2_kernel(const TI* __restrict__ x, int64_t m, int k, int64_t ldx,
                                                          const TI* __restrict__ yy, int n, int64_t ldy,
                                                          float* __restrict__ partial, int64_t chunk)
@@ -780,13 +783,45 @@ __global__ __launch_bounds__(256) void gemm_xty2_kernel(const TI* __restrict__ x
         }
     };
     auto compute = [&](int slot) {
+        if constexpr (SPLIT) {
+            static_assert(U == 8, "one bf16 MFMA step per block of 16 rows");
+            u32x4 xp[KT][3], yp[NT][3];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int a = 0; a < KT; ++a) {
+                unsigned q[3][4];
 #pragma unroll
-            for (int a = 0; a < KT; ++a)
+                for (int pr = 0; pr < 4; ++pr) split3_pair(xa[slot][2 * pr][a], xa[slot][2 * pr + 1][a], q[0][pr], q[1][pr], q[2][pr]);
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
-                    acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[slot][u][a], ya[slot][u][i], acc[a][i], 0, 0, 0);
+                for (int pc = 0; pc < 3; ++pc) xp[a][pc] = u32x4{q[pc][0], q[pc][1], q[pc][2], q[pc][3]};
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                unsigned q[3][4];
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) split3_pair(ya[slot][2 * pr][i], ya[slot][2 * pr + 1][i], q[0][pr], q[1][pr], q[2][pr]);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) yp[i][pc] = u32x4{q[pc][0], q[pc][1], q[pc][2], q[pc][3]};
+            }
+            // (piece of X, piece of Y): smallest products first -- (m,m) (h,l) (l,h) (h,m) (m,h) (h,h)
+            constexpr int PX[6] = {1, 0, 2, 0, 1, 0}, PY[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int a = 0; a < KT; ++a)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+                        acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&xp[a][PX[t6]]),
+                                                                            *reinterpret_cast<const bf16x8_t*>(&yp[i][PY[t6]]),
+                                                                            acc[a][i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int a = 0; a < KT; ++a)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+                        acc[a][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[slot][u][a], ya[slot][u][i], acc[a][i], 0, 0, 0);
+        }
     };
     // row group wr takes blocks wr, wr + WR, ... of 2U rows; two blocks per trip (static register slots)
     const int nblk = (int)((nrows + 2 * U - 1) / (2 * U));
@@ -1272,9 +1307,13 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
         const int wk = k > 32 * kt ? 2 : 1;
         const int wn = (n > 32 * nt && wk == 1) || (n > 32 * nt && k > 32 * kt) ? 2 : 1;
 #define WS_XTY2(KTV, NTV, WKV, WNV)                                                                                   \
-    gemm_xty2_kernel<KTV, NTV, WKV, WNV><<<dim3(chunks, (unsigned)ws_ceil_div(k, 32 * KTV * WKV),                     \
-                                                (unsigned)ws_ceil_div(n, 32 * NTV * WNV)), 256, 0, st>>>(             \
-        x, m, k, ldx, y, n, ldy, partial, chunk)
+    do {                                                                                                              \
+        const dim3 g3(chunks, (unsigned)ws_ceil_div(k, 32 * KTV * WKV), (unsigned)ws_ceil_div(n, 32 * NTV * WNV));    \
+        if (ws_gemm_split)                                                                                            \
+            gemm_xty2_kernel<KTV, NTV, WKV, WNV, float, true><<<g3, 256, 0, st>>>(x, m, k, ldx, y, n, ldy, partial, chunk); \
+        else                                                                                                          \
+            gemm_xty2_kernel<KTV, NTV, WKV, WNV><<<g3, 256, 0, st>>>(x, m, k, ldx, y, n, ldy, partial, chunk);        \
+    } while (0)
 #define WS_XTY2_W(KTV, NTV)                          \
     do {                                             \
         if (wk == 2 && wn == 2) WS_XTY2(KTV, NTV, 2, 2); \
