@@ -103,15 +103,45 @@ __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restri
             const int ch = c0 + 4 * j;
             if (!(sok && ch < c)) continue;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = beg; p < end; ++p) {
+            // a channel of a pooled row takes its maximum from ONE of the h neighbours: of the incoming pairs of s only
+            // ~ 1 / h carry a gradient for a given channel.  So the arg-max pieces of four pairs are fetched together and
+            // a piece of dy only where one of its four channels matches (same sums, in the same order; half the bytes)
+            int p = beg;
+            for (; p + 3 < end; p += 4) {
+                int q4[4], col4[4];
+                int4 a4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pair = t_pairs[p + u];
+                    q4[u] = pair / h;
+                    col4[u] = pair - q4[u] * h;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a4[u] = *reinterpret_cast<const int4*>(arg + (int64_t)q4[u] * c + ch);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int4 a = a4[u];
+                    const int col = col4[u];
+                    if (a.x == col || a.y == col || a.z == col || a.w == col) {
+                        const float4 g = ld4(dy + (int64_t)q4[u] * c + ch);
+                        if (a.x == col) acc.x += g.x;
+                        if (a.y == col) acc.y += g.y;
+                        if (a.z == col) acc.z += g.z;
+                        if (a.w == col) acc.w += g.w;
+                    }
+                }
+            }
+            for (; p < end; ++p) {
                 const int pair = t_pairs[p];
                 const int q = pair / h, col = pair - q * h;
                 const int4 a = *reinterpret_cast<const int4*>(arg + (int64_t)q * c + ch);
-                const float4 g = ld4(dy + (int64_t)q * c + ch);
-                if (a.x == col) acc.x += g.x;
-                if (a.y == col) acc.y += g.y;
-                if (a.z == col) acc.z += g.z;
-                if (a.w == col) acc.w += g.w;
+                if (a.x == col || a.y == col || a.z == col || a.w == col) {
+                    const float4 g = ld4(dy + (int64_t)q * c + ch);
+                    if (a.x == col) acc.x += g.x;
+                    if (a.y == col) acc.y += g.y;
+                    if (a.z == col) acc.z += g.z;
+                    if (a.w == col) acc.w += g.w;
+                }
             }
             st4(dx + s * c + ch, acc);
         }
