@@ -107,6 +107,14 @@ int linear_fwd(const Lin& l, const float* x, int64_t m, int64_t ldx, const float
 struct TimerRec { hipEvent_t a, b, c; int64_t nq; int32_t h, ci; };      // a .. b: the K3 launch, a .. c: K3 + the contraction
 std::vector<TimerRec>& timer_recs() { static std::vector<TimerRec> v; return v; }
 
+// the strided block's arg-max record lives in the block's own arena slot (only ws_kpblock_bwd reads it): bytes when the
+// neighbour columns fit one (4x fewer bytes for the backward's per-pair reads), the forward and the backward decide alike
+bool arg_bytes(const ws_kpblock* d)
+{
+    return d->h <= 255 && d->in_dim % 4 == 0 && ((uintptr_t)d->feat & 15u) == 0 && ((uintptr_t)d->pooled & 15u) == 0 &&
+           ((uintptr_t)d->arg & 3u) == 0;
+}
+
 int check_kpblock(const ws_kpblock* d)
 {
     WS_REQUIRE(d, "NULL descriptor");
@@ -172,7 +180,10 @@ int kpblock_fwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     if (!d->w2) return WS_OK;
     const float* sc_in = d->feat;
     if (d->strided) {
-        WS_TRY(ws_max_pool_fwd(d->feat, ns, d->in_dim, d->inds, nq, d->h, d->pooled, d->arg, st));
+        if (arg_bytes(d))
+            WS_TRY(ws_priv_max_pool_fwd_u8(d->feat, ns, d->in_dim, d->inds, nq, d->h, d->pooled, reinterpret_cast<uint8_t*>(d->arg), st));
+        else
+            WS_TRY(ws_max_pool_fwd(d->feat, ns, d->in_dim, d->inds, nq, d->h, d->pooled, d->arg, st));
         sc_in = d->pooled;
     }
     const float* res = sc_in;
@@ -262,7 +273,11 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
             }
             if (d->strided) {
                 WS_REQUIRE(d->t_offsets && d->t_pairs, "strided block backward needs the transposed table");
-                WS_TRY(ws_max_pool_bwd(dsc, d->arg, nq, d->h, d->in_dim, d->t_offsets, d->t_pairs, ns, dfsc, st));
+                if (arg_bytes(d))
+                    WS_TRY(ws_priv_max_pool_bwd_u8(dsc, reinterpret_cast<const uint8_t*>(d->arg), nq, d->h, d->in_dim, d->t_offsets,
+                                                   d->t_pairs, ns, dfsc, st));
+                else
+                    WS_TRY(ws_max_pool_bwd(dsc, d->arg, nq, d->h, d->in_dim, d->t_offsets, d->t_pairs, ns, dfsc, st));
                 sc_res = dfsc;
             } else {
                 sc_res = dsc;

@@ -9,14 +9,22 @@ namespace {
 
 __device__ __forceinline__ int64_t ws_ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ int4 load_arg4(const int32_t* p) { return *reinterpret_cast<const int4*>(p); }
+__device__ __forceinline__ int4 load_arg4(const uint8_t* p)
+{
+    const unsigned w = *reinterpret_cast<const unsigned*>(p);
+    return make_int4((int)(w & 0xffu), (int)((w >> 8) & 0xffu), (int)((w >> 16) & 0xffu), (int)(w >> 24));
+}
 
 // VEC path (c % 4 == 0, 16-byte aligned rows): G = c/4 lanes (capped at 64) cover one row with
 // float4 pieces, 64/G query rows per wave, the neighbour loop unrolled by 4 so that four row
 // gathers are in flight per lane; shadow columns read nothing (zero row, blocks.py:104).
-template <int G, typename T>
+// AT = the element type of the arg-max record: int32 (the C ABI), or uint8 inside the block calls when h <= 255 -- the
+// backward reads one arg piece per (incoming pair, row piece), 2.7 GB at level 0 with 4-byte elements
+template <int G, typename T, typename AT = int32_t>
 __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restrict__ x, int64_t ns, int c,
                                                                 const int64_t* __restrict__ inds, int64_t nq, int h,
-                                                                T* __restrict__ out, int32_t* __restrict__ arg)
+                                                                T* __restrict__ out, AT* __restrict__ arg)
 {
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -51,7 +59,13 @@ __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restri
             }
             if (ok) {
                 st4(out + q * c + ch, best);
-                if (arg) *reinterpret_cast<int4*>(arg + q * c + ch) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+                if (arg) {
+                    if constexpr (sizeof(AT) == 4)
+                        *reinterpret_cast<int4*>(arg + q * c + ch) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+                    else
+                        *reinterpret_cast<unsigned*>(arg + q * c + ch) =
+                            (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+                }
             }
         }
     }
@@ -84,8 +98,8 @@ __global__ __launch_bounds__(256) void max_pool_fwd_kernel(const T* __restrict__
 }
 
 // backward, VEC path: G lanes x float4 per support row, 64/G supports per wave
-template <int G, typename T>
-__global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restrict__ dy, const int32_t* __restrict__ arg,
+template <int G, typename T, typename AT = int32_t>
+__global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restrict__ dy, const AT* __restrict__ arg,
                                                                 int h, int c, const int32_t* __restrict__ t_offsets,
                                                                 const int32_t* __restrict__ t_pairs, int64_t ns,
                                                                 T* __restrict__ dx)
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restri
                     col4[u] = pair - q4[u] * h;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a4[u] = *reinterpret_cast<const int4*>(arg + (int64_t)q4[u] * c + ch);
+                for (int u = 0; u < 4; ++u) a4[u] = load_arg4(arg + (int64_t)q4[u] * c + ch);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int4 a = a4[u];
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restri
             for (; p < end; ++p) {
                 const int pair = t_pairs[p];
                 const int q = pair / h, col = pair - q * h;
-                const int4 a = *reinterpret_cast<const int4*>(arg + (int64_t)q * c + ch);
+                const int4 a = load_arg4(arg + (int64_t)q * c + ch);
                 if (a.x == col || a.y == col || a.z == col || a.w == col) {
                     const float4 g = ld4(dy + (int64_t)q * c + ch);
                     if (a.x == col) acc.x += g.x;
@@ -248,6 +262,33 @@ int max_pool_bwd_impl(const T* dy, const int32_t* arg, int64_t nq, int32_t h, in
     return WS_OK;
 }
 
+// the block calls' private form: arg-max record in bytes (h <= 255, c % 4 == 0, aligned rows: the caller checks)
+int max_pool_fwd_u8_impl(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, float* out, uint8_t* arg,
+                         hipStream_t st)
+{
+    if (nq == 0) return WS_OK;
+    if (c <= 16) max_pool_fwd_vec_kernel<4, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 16), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (c <= 32) max_pool_fwd_vec_kernel<8, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 8), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (c <= 64) max_pool_fwd_vec_kernel<16, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 4), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else if (c <= 128) max_pool_fwd_vec_kernel<32, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 2), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    else max_pool_fwd_vec_kernel<64, float, uint8_t><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+int max_pool_bwd_u8_impl(const float* dy, const uint8_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                         const int32_t* t_pairs, int64_t ns, float* dx, hipStream_t st)
+{
+    (void)nq;
+    if (ns == 0) return WS_OK;
+    if (c <= 32) max_pool_bwd_vec_kernel<8, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 8), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else if (c <= 64) max_pool_bwd_vec_kernel<16, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 4), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else if (c <= 128) max_pool_bwd_vec_kernel<32, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 2), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    else max_pool_bwd_vec_kernel<64, float, uint8_t><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
 template <typename T>
 int closest_pool_fwd_impl(const T* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
                           T* out, void* stream)
@@ -325,6 +366,20 @@ int ws_closest_pool_bwd_bf16(const uint16_t* dy, int64_t nq, int32_t h, int32_t 
 {
     return closest_pool_bwd_impl<bf16_t>(reinterpret_cast<const bf16_t*>(dy), nq, h, c, t_offsets, t_pairs, ns,
                                          reinterpret_cast<bf16_t*>(dx), stream);
+}
+
+// private to the library (declared in ws_common.h, not part of include/weasal_hip.h): the block calls keep their arg-max
+// record in bytes.  Preconditions (checked by the caller): h <= 255, c % 4 == 0, 16-byte aligned rows, 4-byte aligned arg.
+int ws_priv_max_pool_fwd_u8(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, float* out,
+                            uint8_t* arg, void* stream)
+{
+    return max_pool_fwd_u8_impl(x, ns, c, inds, nq, h, out, arg, (hipStream_t)stream);
+}
+
+int ws_priv_max_pool_bwd_u8(const float* dy, const uint8_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                            const int32_t* t_pairs, int64_t ns, float* dx, void* stream)
+{
+    return max_pool_bwd_u8_impl(dy, arg, nq, h, c, t_offsets, t_pairs, ns, dx, (hipStream_t)stream);
 }
 
 }  // extern "C"
