@@ -114,3 +114,31 @@ def test_fused_sgd_hands_unsupported_cases_to_torch(gpu):
         a.step(clip_value=1.0)
         b.step()
     assert torch.equal(p.detach(), q.detach())
+
+
+def test_run_ahead_limiter_reports_a_set_capacity_flag(gpu):
+    """InFlightLimiter folds the K4G capacity flags of the batches on the device and looks at them off the step: a set flag
+    raises at the periodic check (after check_every + depth ticks at the latest) or in finish(), a clean run stays silent"""
+    import types
+    from weasal_amd.trainer import InFlightLimiter
+
+    def batch(value, grids=3):
+        return types.SimpleNamespace(search_grids=[(None, types.SimpleNamespace(overflow=torch.full((1,), value, dtype=torch.int32, device=gpu)))
+                                                   for _ in range(grids)])
+
+    lim = InFlightLimiter(depth=2, check_every=4)
+    for _ in range(12):
+        lim.tick(batch(0))
+    lim.finish()
+    lim = InFlightLimiter(depth=2, check_every=4)
+    lim.tick(batch(0))
+    lim.tick(batch(300))                       # folded into the running maximum, not yet on the host
+    with pytest.raises(RuntimeError, match="overflowed"):
+        for _ in range(8):
+            lim.tick(batch(0))
+    lim = InFlightLimiter(depth=2, check_every=100)
+    lim.tick(batch(0))
+    lim.tick(batch(7, grids=2))                # another number of grids: the folded flags go out at once
+    lim.tick(batch(300, grids=2))
+    with pytest.raises(RuntimeError, match="300"):
+        lim.finish()

@@ -149,8 +149,12 @@ class InFlightLimiter:
         self._ticks += 1
         if grids:
             dev = torch.cat([g.overflow for _, g in grids])
-            self._acc = dev if (self._acc is None or self._acc.shape != dev.shape) else torch.maximum(self._acc, dev)
-        if self._acc is not None and self._ticks % self.check_every == 0:
+            if self._acc is not None and self._acc.shape != dev.shape:
+                flags = self._land(self._acc)        # another number of grids than before: what was folded so far goes out now
+                self._acc = dev
+            else:
+                self._acc = dev if self._acc is None else torch.maximum(self._acc, dev)
+        if flags is None and self._acc is not None and self._ticks % self.check_every == 0:
             flags = self._land(self._acc)
             self._acc = None
         e = torch.cuda.Event()
