@@ -261,7 +261,9 @@ def main():
         pyramid.ACTIVATE_STALLS = []
     waits["prefetch"] = waits["limiter"] = 0.0
     fused.timer_reset()
-    fused.set_timed(True)            # HIP events around the K3 launches inside the block calls (launch stream)
+    # HIP events around the K3 launches inside the block calls (launch stream); WEASAL_TIMED_MIN_ROWS: only layers with at
+    # least that many query rows (A/B of the events' own cost)
+    fused.set_timed(True, int(os.environ.get("WEASAL_TIMED_MIN_ROWS", "0")))
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)

@@ -22,10 +22,16 @@ FUSED_BLOCKS = os.environ.get("WEASAL_FUSED_BLOCKS", "1") != "0"      # A/B swit
 _timed = False
 
 
-def set_timed(on):
-    """bench.py: bracket every K3 launch inside the block calls with HIP events (ws_timer_*)"""
-    global _timed
+_timed_min_rows = 0
+
+
+def set_timed(on, min_rows=0):
+    """bench.py: bracket the K3 launch (and the contraction after it) inside the block calls with HIP events (ws_timer_*);
+    min_rows: only layers with at least that many query rows (every event is a marker packet on the launch stream:
+    timing all ~25 layers of a step costs more than it tells)"""
+    global _timed, _timed_min_rows
     _timed = bool(on)
+    _timed_min_rows = int(min_rows)
 
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -152,7 +158,7 @@ class _KPBlockFn(torch.autograd.Function):
         d.pooled = base + 4 * offs[3] if sizes[3] else None
         d.arg = base + 4 * offs[4] if sizes[4] else None
         d.out = out.data_ptr()
-        d.timed = 1 if _timed else 0
+        d.timed = 1 if (_timed and g.q_pts.shape[0] >= _timed_min_rows) else 0
         nbytes = lib.ws_kpblock_fwd_scratch_bytes(C.byref(d))
         if nbytes < 0:
             check(1)
