@@ -267,7 +267,7 @@ def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linea
 # ------------------------------------------------------------------------------------------------
 FUSED_EPILOGUE = os.environ.get("WEASAL_FUSED_EPILOGUE", "1") != "0"   # A/B switch (diagnostics)
 GEMM_MIN_ROWS = int(os.environ.get("WEASAL_GEMM_MIN_ROWS", "0"))        # A/B switch (diagnostics): fewer rows -> torch.matmul (library GEMM); default: never
-XTY_MIN_ROWS = 0         # A/B switch: rows below which dW = x^T dy goes to rocBLAS (in the training step the MFMA
+XTY_MIN_ROWS = 0         # A/B switch: rows below which dW = x^T dy goes to the library GEMM (in the training step the MFMA
                          # reduction is ahead at every level that reaches it: 0.42 ms vs 0.54 ms per step at M = 10 257)
 
 
@@ -295,7 +295,8 @@ def _xb_launch(lib, x, m, k, b, n, bias, residual, slope, y):
 
 
 def _gemm_xty(lib, x, dy):
-    """x^T @ dy: the LDS-free MFMA reduction for tall operands, rocBLAS (TN) for short ones"""
+    """x^T @ dy: the LDS-free MFMA reduction (rows split per workgroup: gemm.hip xty_chunk); XTY_MIN_ROWS > 0 is a
+    diagnostics switch to the library GEMM for shorter operands"""
     m, k = x.shape
     n = dy.shape[1]
     if m < XTY_MIN_ROWS:
