@@ -203,3 +203,107 @@ def test_vaihingen_real_widths_pyramid_and_step_vs_oracle(gpu):
     ref = dict(net_cpu.named_parameters())
     for name, p in net.named_parameters():
         assert _rel(p, ref[name]) < 1e-4, name
+
+
+def test_full_size_gather_is_adjoint_and_linear(gpu):
+    """BASELINE config 3 at its FULL size (8 x 50 000-point spheres, limits 59/73/...): size-independent properties of the
+    gather kernels, where the oracle is too slow to follow.  The KPConv weighted-feature map x -> wf is linear, and its
+    backward must be its adjoint:  <wf(x), g> = <x, dx(g)>  for every level's self-query layer (K3 against K4G -- candidates
+    from the supports' own rows and from the grid walk, truncated rows included) and for the strided layer of level 0
+    (K3 against the table form K4).  float64 inner products; 2e-5 relative (fp32 sums in different orders)."""
+    from weasal_amd import config as wcfg, ops, pyramid, synthetic
+    from weasal_amd.kernel_points import load_kernels
+    cfg = wcfg.DALESPLConfig()
+    wl = synthetic.WORKLOADS["dales"]
+    pts, feats, labels, lens = synthetic.make_inputs(77, wl["spheres"], wl["points"], wl["radius"], cfg.in_features_dim)
+    np.random.seed(3)
+    batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu), torch.from_numpy(labels).to(gpu),
+                                lens, wl["limits"])
+    batch.activate()
+    assert batch.points[0].shape[0] == 400000 and len(batch.search_grids) >= 4
+    torch.manual_seed(5)
+    checked = 0
+    for lvl, ci in ((0, 32), (1, 64), (2, 128), (3, 256)):
+        r = cfg.first_subsampling_dl * cfg.conv_radius * 2 ** lvl
+        extent = r * cfg.KP_extent / cfg.conv_radius
+        kp = torch.from_numpy(load_kernels(r, 15, dimension=3, fixed="center").astype(np.float32)).to(gpu)
+        cases = [(batch.points[lvl], batch.points[lvl], batch.neighbors[lvl])]
+        if lvl == 0:
+            cases.append((batch.points[1], batch.points[0], batch.pools[0]))          # strided: queries of level 1, table form
+        for q_pts, s_pts, inds in cases:
+            x = torch.randn(s_pts.shape[0], ci, device=gpu, requires_grad=True)
+            y = torch.randn(s_pts.shape[0], ci, device=gpu)
+            wf, _ = ops.kpconv_gather(x, q_pts, s_pts, inds, kp, extent)
+            g = torch.randn_like(wf)
+            dx, = torch.autograd.grad(wf, x, g)
+            lhs = float((wf.detach().double() * g.double()).sum())
+            rhs = float((x.detach().double() * dx.double()).sum())
+            # both sides are sums of n random-sign terms: their size, and the size of an fp32 error of 1e-6 per element, scale
+            # with |wf| |g| / sqrt(n)
+            scale = float(wf.detach().double().norm() * g.double().norm()) / wf.numel() ** 0.5
+            assert abs(lhs - rhs) <= 2e-5 * scale, (lvl, lhs, rhs, scale)
+            # linearity: wf(2 x - 3 y) = 2 wf(x) - 3 wf(y)
+            wy, _ = ops.kpconv_gather(y, q_pts, s_pts, inds, kp, extent)
+            wz, _ = ops.kpconv_gather(2.0 * x.detach() - 3.0 * y, q_pts, s_pts, inds, kp, extent)
+            ref = 2.0 * wf.detach() - 3.0 * wy
+            assert float((wz - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), lvl
+            checked += 1
+    assert checked == 5
+    for _, grid in batch.search_grids:
+        assert int(grid.overflow.item()) == 0
+
+
+def test_full_size_pools_and_products_properties(gpu):
+    """the same full-size batch: properties of the pooling kernels and the dense products that need no oracle --
+    closest_pool is linear with its backward as adjoint; every max_pool output is attained by one of its row's sources
+    and its backward routes each gradient entry to exactly that source (column sums preserved); the three products of a
+    layer are mutually adjoint, <x W, g> = <W, x^T g> = <x, g W^T>; the loss gradient rows sum to zero."""
+    from weasal_amd import config as wcfg, ops, pyramid, synthetic
+    cfg = wcfg.DALESPLConfig()
+    wl = synthetic.WORKLOADS["dales"]
+    pts, feats, labels, lens = synthetic.make_inputs(78, wl["spheres"], wl["points"], wl["radius"], cfg.in_features_dim)
+    np.random.seed(4)
+    batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu), torch.from_numpy(labels).to(gpu),
+                                lens, wl["limits"])
+    batch.activate()
+    torch.manual_seed(6)
+    n0, n1 = batch.points[0].shape[0], batch.points[1].shape[0]
+    # ---- nearest upsampling (level 1 -> 0): linear, adjoint backward
+    xc = torch.randn(n1, 128, device=gpu, requires_grad=True)
+    up = ops.closest_pool(xc, batch.upsamples[0])
+    g = torch.randn_like(up)
+    dxc, = torch.autograd.grad(up, xc, g)
+    lhs, rhs = float((up.detach().double() * g.double()).sum()), float((xc.detach().double() * dxc.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float(up.detach().double().norm() * g.double().norm()) / up.numel() ** 0.5
+    # ---- max pooling (level 0 -> 1)
+    x = torch.randn(n0, 128, device=gpu, requires_grad=True)
+    pooled = ops.max_pool(x, batch.pools[0])
+    xs = torch.cat([x.detach(), torch.zeros(1, 128, device=gpu)])          # the shadow row (blocks.py:104)
+    probe = torch.arange(0, n1, 97, device=gpu)                            # a sample of rows: every output is the max of its sources
+    gathered = xs[batch.pools[0][probe]]
+    assert torch.equal(pooled.detach()[probe], gathered.max(dim=1).values)
+    gp = torch.randn_like(pooled)
+    dx, = torch.autograd.grad(pooled, x, gp)
+    routed = float(dx.double().sum())                                      # entries whose maximum is the shadow row are dropped
+    hit_shadow = pooled.detach() == 0.0
+    kept = float((gp.double() * (~hit_shadow)).sum())
+    assert abs(routed - kept) <= 1e-6 * float(gp.double().abs().sum())
+    # ---- the three products of a 400 000-row layer are mutually adjoint
+    xw = torch.randn(n0, 128, device=gpu)
+    w = torch.randn(128, 128, device=gpu) / 128 ** 0.5
+    gy = torch.randn(n0, 128, device=gpu)
+    y = ops._gemm_xb(xw, w)
+    dw = ops._gemm_xty(ops._lib.lib(), xw, gy)
+    dxw = ops._gemm_xb(gy, w.t().contiguous())
+    a = float((y.double() * gy.double()).sum())
+    b = float((w.double() * dw.double()).sum())
+    c = float((xw.double() * dxw.double()).sum())
+    scale = float(y.double().norm() * gy.double().norm()) / y.numel() ** 0.5
+    assert abs(a - b) <= 2e-5 * scale and abs(a - c) <= 2e-5 * scale
+    # ---- loss: rows of the gradient sum to zero (softmax - one-hot), ignored rows are zero
+    logits = torch.randn(n0, 9, device=gpu, requires_grad=True)
+    lab = torch.randint(-1, 9, (n0,), device=gpu)
+    loss = ops.cross_entropy(logits, lab)
+    dl, = torch.autograd.grad(loss, logits)
+    assert float(loss.detach()) > 0 and float(dl.sum(dim=1).abs().max()) <= 1e-9
+    assert float(dl[lab < 0].abs().sum()) == 0.0
