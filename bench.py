@@ -15,9 +15,12 @@ Besides the contract line this prints, in the same JSON object:
   cpu_baseline  the CPU path (reference geometry core from oracle/_ref when present, else the port;
                 plain-torch KPConv restatement) timed on this box's host cores on ONE sphere.
 
-Launch: `python bench.py` (1 GPU) or
+Launch: `python bench.py` (1 GPU), or for N ranks either
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
+or plainly `python bench.py --gpus N ...`: without WORLD_SIZE in the environment this process touches no GPU, starts the
+N ranks itself as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's JSON line and
+exits non-zero if any rank fails.
 """
 import argparse
 import json
@@ -148,6 +151,46 @@ def cpu_baseline(cfg_cls, wl, threads):
                       % (n, t_pyr, "oracle/_ref = the reference's own C++" if kind == "ref" else "oracle port", t_model, threads)}
 
 
+def self_launch(n):
+    """`--gpus N` without a launcher: start the N ranks as FRESH child processes of this one, which has made no GPU call
+    (importing torch and counting devices does not initialise HIP; a process that did must never be re-executed).
+    Rank 0's stdout (the JSON line) and every rank's stderr are relayed; the exit code is the first non-zero one."""
+    import socket
+    import subprocess
+    backend = os.environ.get("WEASAL_DIST_BACKEND", "")
+    ndev = torch.cuda.device_count()
+    if backend != "gloo" and ndev < n:
+        print("bench.py --gpus %d: only %d GPU(s) visible; RCCL needs one GPU per rank (WEASAL_DIST_BACKEND=gloo lets "
+              "ranks share a GPU for a rehearsal)" % (n, ndev), file=sys.stderr)
+        return 2
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in procs:             # a dead rank leaves the others waiting in a collective
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,6 +211,8 @@ def main():
                          "current step trains (weasal_amd.prefetch, the GPU counterpart of the reference's DataLoader "
                          "workers); 0: pyramid and training strictly one after the other on one stream")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch.distributed as dist
     from weasal_amd import config as wcfg, dp, ops, pyramid, synthetic
@@ -177,8 +222,8 @@ def main():
     if args.blas:
         torch.backends.cuda.preferred_blas_library(args.blas)
     rank, local_rank, world = dp.init_from_env()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (% only matters for gloo rehearsals)
     torch.cuda.set_device(dev)
@@ -193,6 +238,8 @@ def main():
     dp.broadcast_parameters(net)
     opt = make_optimizer(net, cfg)
     sync = dp.GradSync(buckets=args.dp_buckets) if world > 1 else None
+    if sync is not None:
+        sync.timed = True          # HIP events around the exchange (reported as config.allreduce_ms)
 
     # inputs resident in HBM before the timed region (seed = 1000*rank + step)
     nd = max(1, min(args.distinct_batches, args.steps + args.warmup))
@@ -308,7 +355,13 @@ def main():
                           + ("; contrast_loss term included" if args.contrast else "; contrast_loss term (trainer_PseudoLabel.py:204-208) not in this step, see --contrast 1")
                           + ("; pyramid of the next batch overlapped on a second stream" if args.prefetch else ""),
                           "points_per_step_per_gpu": n_points, "parallelism": "dp%d" % world,
-                          "dist_backend": backend, "final_loss": float(loss.item())}}
+                          "dist_backend": backend,
+                          # what the process group itself says (not the flag): ranks that took part in the exchange
+                          "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                          "allreduce_bytes": sync.nbytes() if sync is not None else 0,
+                          "allreduce_ms": sync.mean_ms() if sync is not None else None,
+                          "host_threads_per_rank": "1 training + %d pyramid prefetch" % (prefetcher.workers if prefetcher is not None else 0),
+                          "final_loss": float(loss.item())}}
         # ---- roofline of the fused KPConv gather kernel (K3) on the largest layer: HIP events on the launch stream,
         #      recorded inside the block calls (ws_timer_*) or around the operator launch (ops timer)
         summ = timer.summary()

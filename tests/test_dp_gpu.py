@@ -75,3 +75,24 @@ def test_rccl_branch_runs_on_one_rank_and_leaves_the_step_unchanged(gpu):
     for k in ref:
         assert torch.equal(ref[k], one[k]), k          # sum over one rank, / 1: the same gradients, the same update
         assert torch.equal(ref[k], four[k]), k
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent touches no GPU, starts two fresh rank
+    processes, relays rank 0's line.  On this one-GPU box the two ranks share the card over gloo (the rehearsal backend);
+    what is pinned is the launch path and that the line describes the group that really ran (n_gpus, dist_world_size)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WEASAL_DIST_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--workload", "vaihingen"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["dist_world_size"] == 2
+    assert out["config"]["dist_backend"] == "gloo" and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["allreduce_bytes"] == 4 * 4097993          # the Vaihingen KPFCNN's flat fp32 gradient (SURVEY App. B)
+    assert out["scaling"] == "weak" and out["value"] > 0

@@ -94,6 +94,17 @@ class GradSync:
         self._sig_local = None
         self._sig_check = None   # (pinned host sums, event, expected) of the previous call
         self._host = None
+        self.timed = False       # bench.py: HIP events around the exchange (GPU tensors only)
+        self._times = []
+
+    def mean_ms(self):
+        """mean duration of the exchanges timed so far (HIP events on the stream the all-reduce was issued from:
+        buckets == 1 only -- the overlapped form's ranges run under backward); None without records"""
+        if not self._times:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self._times]
+        self._times = []
+        return float(sum(ms) / len(ms))
 
     # ---- layout ---------------------------------------------------------------------------------------------
     def _layout(self, net):
@@ -249,7 +260,15 @@ class GradSync:
             self._handles = []
             self._launched = [False] * len(self._ranges)
         else:
+            ev = None
+            if self.timed and self.flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if ev is not None:
+                ev[1].record()
+                self._times.append(ev)
+                del self._times[:-64]
         self._armed = self._ran = False
         self.flat[:self.total].div_(world)
         # the summed signature travels to the host asynchronously and is checked at the next call
