@@ -1,0 +1,300 @@
+"""GPU parity of BASELINE config 5 ("DALES deformable-KPConv bf16") AT ITS REAL NEIGHBOUR WIDTHS.
+
+Every `resnetb` of config 5 is deformable + modulated, so every level is searched with the deformable radius
+(datasets/common.py:498-503: r * deform_radius / conv_radius = 2 r, about 8 x the neighbours); the calibrated limits of
+the synthetic workload are 422 / 519 / 472 / 193 / 34 (weasal_amd/synthetic.py).  Rows that wide take code paths the
+<= 128-column tests never touch: the wide-row neighbour search, K3 accumulating over several 64-column chunks with
+per-query kernel points, the backward over in-degrees of several hundred pairs, the geometry backward K6.  This file
+pins them against the CPU oracle (oracle/geom.py = the reference's compiled C++ core when oracle/_ref is present,
+oracle/kpconv_ref.py = the reference's op sequence in plain torch, oracle/pyramid_ref.py):
+
+  * neighbour search at width > 400, with and without a limit                        -> bit-exact (ties: conftest)
+  * the device pyramid of one 50 000-point sphere at the workload's limits           -> bit-exact index matrices
+  * deformable + modulated KPConv forward / backward at H = 422 / 519 / 472, self-query (table-free backward) and
+    strided (transposed table) layers, Ci = 32 / 64 / 128:
+        f32 rows   out 1e-4, dx / dW 1e-4, gradients through the learned offsets 5e-4   
+        bf16 rows  against the fp32 oracle on bf16-rounded operands, bounds of tests/test_bf16_gpu.py
+  * the full-size workload (8 x 50 000 points): adjointness / linearity of the deformed gather on every level.
+Reference units: models/blocks.py:244-325, 366-367; datasets/common.py:500-502; models/architectures.py:24-57.
+"""
+import copy
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_neighbors_equal, sphere
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+LIMITS = [422, 519, 472, 193, 34]
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "config5_parity.json")
+
+
+def rel(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def rel2(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return ((a - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+def rbf(t):
+    return t.to(BF).to(torch.float32)
+
+
+def _report(key, values):
+    """measured errors of this run, kept next to the pass / fail (read by DESIGN.md section 2)"""
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        data = json.load(open(REPORT)) if os.path.exists(REPORT) else {}
+        data[key] = values
+        json.dump(data, open(REPORT, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K1 at width > 400
+# ---------------------------------------------------------------------------------------------------------------------
+def _dense_clouds(seed, n=(9000, 7000), R=5.0):
+    rng = np.random.default_rng(seed)
+    pts = np.concatenate([sphere(rng, n[0], R), sphere(rng, n[1], R, center=(40, 0, 0))]).astype(np.float32)
+    return pts, np.array(n, np.int32)
+
+
+@pytest.mark.parametrize("limit", [None, 422, 519])
+def test_wide_row_search_vs_oracle(gpu, limit):
+    """radius search whose rows hold 300-600 neighbours (17 points / m^3, r = 1.9): the full-width two-call protocol and the
+    one-pass limited search against the CPU oracle (neighbors.cpp:211-332), bit-exact"""
+    from oracle import geom
+    from weasal_amd import ops
+    pts, lens = _dense_clouds(1)
+    r = 1.9
+    want = geom.batch_query(pts, pts, lens, lens, r, kind="ref" if geom.have_ref() else "port")
+    assert want.shape[1] > 512            # beyond the 512-entry slab too
+    P = torch.from_numpy(pts).to(gpu)
+    got = ops.radius_neighbors(P, P, lens, lens, r, limit=limit, dtype=torch.int64).cpu().numpy()
+    if limit is not None:
+        want = want[:, :limit]
+    assert got.shape == want.shape
+    assert_neighbors_equal(pts, pts, got, want.astype(np.int64), False)
+    # the asynchronous form the pyramid uses (no host synchronisation; widths checked at the end)
+    if limit is not None:
+        d = ops.DeferredSearches(gpu)
+        d.add(P, P, lens, lens, r, limit, want_order=True, want_grid=True)
+        sub = P[::3].contiguous()
+        sl = np.array([len(range(0, int(lens[0]), 3)), 0], np.int32)
+        sl[1] = sub.shape[0] - sl[0]
+        d.add(sub, P, sl, lens, r, limit)                          # queries != supports (a strided layer's search)
+        fin = d.finish()
+        assert_neighbors_equal(pts, pts, fin[0].cpu().numpy(), want.astype(np.int64), False)
+        subw = geom.batch_query(pts[::3], pts, sl, lens, r)[:, :limit]
+        assert_neighbors_equal(pts[::3], pts, fin[1].cpu().numpy(), subw.astype(np.int64), False)
+        assert d.last_counts[0] == geom.batch_query(pts, pts, lens, lens, r).shape[1]
+
+
+@pytest.mark.timeout(1500)
+def test_config5_pyramid_at_real_limits_vs_oracle(gpu):
+    """ONE 50 000-point sphere of the config-5 workload through pyramid.build_batch with the workload's limits: every
+    points / neighbours / pools / upsamples matrix against oracle.pyramid_ref (datasets/common.py:461-577 with the
+    deformable radius of :500-502), bit-exact up to exact-distance ties"""
+    from oracle import geom, pyramid_ref
+    from weasal_amd import config as wcfg, pyramid, synthetic
+    cfg = wcfg.DALESDeformConfig()
+    wl = synthetic.WORKLOADS["dales_deform"]
+    assert wl["limits"] == LIMITS
+    pts, feats, labels, lens = synthetic.make_inputs(31, 1, wl["points"], wl["radius"], cfg.in_features_dim)
+    np.random.seed(17)
+    batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu),
+                                torch.from_numpy(labels).to(gpu), lens, LIMITS)
+    np.random.seed(17)
+    li = pyramid_ref.segmentation_inputs(cfg, pts, feats, labels, lens, LIMITS, kind="ref" if geom.have_ref() else "port")
+    L = cfg.num_layers
+    assert L == 5 and batch.neighbors[0].shape == (50000, 422) and batch.neighbors[1].shape[1] == 519
+    for l in range(L):
+        p_l = li[l]
+        assert np.array_equal(batch.points[l].cpu().numpy(), p_l), l
+        assert_neighbors_equal(p_l, p_l, batch.neighbors[l].cpu().numpy(), li[L + l], False)
+        if l < L - 1:
+            nxt = li[l + 1]
+            assert_neighbors_equal(nxt, p_l, batch.pools[l].cpu().numpy(), li[2 * L + l], False)
+            assert_neighbors_equal(p_l, nxt, batch.upsamples[l].cpu().numpy(), li[3 * L + l], False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# deformable + modulated KPConv at H = 422 / 519 / 472
+# ---------------------------------------------------------------------------------------------------------------------
+_BATCH = {}
+
+
+def _small_dense_batch(gpu):
+    """a sphere with the DALES level-0 density (11.9 points / m^3) but only 7 000 points, through the config-5 pyramid with
+    the workload's limits: level 0 rows are truncated at 422, level 1 at 519 (what the limits do at full size), small
+    enough for the CPU oracle's [N, H, 15, 3] tensors"""
+    if "b" not in _BATCH:
+        from weasal_amd import config as wcfg, pyramid
+        cfg = wcfg.DALESDeformF32Config()
+        rng = np.random.default_rng(5)
+        pts = sphere(rng, 7000, 5.2)
+        feats = np.ones((7000, 3), np.float32)
+        labels = np.zeros(7000, np.int64)
+        np.random.seed(2)
+        batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu),
+                                    torch.from_numpy(labels).to(gpu), np.array([7000], np.int32), LIMITS)
+        _BATCH["b"] = (cfg, batch)
+    return _BATCH["b"]
+
+
+def _layer_pair(gpu, ci, co, extent, radius, bf16):
+    """deformable + modulated KPConv on the GPU and its CPU twin (bf16 rows: the twin holds the bf16-rounded weights)"""
+    from weasal_amd.blocks import KPConv
+    np.random.seed(1)
+    torch.manual_seed(1)
+    conv = KPConv(15, 3, ci, co, extent, radius, deformable=True, modulated=True)
+    with torch.no_grad():                   # offsets of a useful size (the zero-mean init gives ~0.01 extents)
+        conv.offset_conv.weights.mul_(4.0 * (32.0 / ci) ** 0.5)
+        conv.offset_bias.normal_(0.0, 0.05)
+    twin = copy.deepcopy(conv)
+    if bf16:
+        with torch.no_grad():
+            twin.weights.copy_(rbf(twin.weights))
+            twin.offset_conv.weights.copy_(rbf(twin.offset_conv.weights))
+    return conv.to(gpu), twin
+
+
+CASES = [("self", 0, 32), ("strided", 0, 32), ("self", 1, 64), ("strided", 1, 64), ("self", 2, 128)]
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("rows", ["f32", "bf16"])
+@pytest.mark.parametrize("kind,lvl,ci", CASES)
+def test_deformable_kpconv_real_width_vs_oracle(gpu, kind, lvl, ci, rows):
+    from oracle import kpconv_ref
+    from weasal_amd import ops
+    from weasal_amd.architectures import p2p_fitting_regularizer
+    cfg, batch = _small_dense_batch(gpu)
+    batch.activate()
+    bf = rows == "bf16"
+    r = cfg.first_subsampling_dl * cfg.conv_radius * 2 ** lvl
+    extent = r * cfg.KP_extent / cfg.conv_radius
+    if kind == "self":
+        q_pts = s_pts = batch.points[lvl]
+        inds = batch.neighbors[lvl]
+    else:
+        q_pts, s_pts, inds = batch.points[lvl + 1], batch.points[lvl], batch.pools[lvl]
+    h = inds.shape[1]
+    assert h == min(LIMITS[lvl], h) and (lvl > 1 or h == LIMITS[lvl]), (lvl, h)
+    if kind == "self" and ops.GRID_BACKWARD and lvl < 2 and os.environ.get("WEASAL_EXPECT_WIDE_GRID", "1") != "0":
+        assert ops._grid_for(inds) is not None, "the wide self-query layer must take the table-free backward"
+    conv, twin = _layer_pair(gpu, ci, ci, extent, r, bf)
+    torch.manual_seed(4 + lvl)
+    x = torch.randn(s_pts.shape[0], ci, device=gpu)
+    dy = torch.randn(q_pts.shape[0], ci, device=gpu)
+    if bf:
+        x, dy = x.to(BF), dy.to(BF)
+    xg = x.clone().requires_grad_(True)
+    out = conv(q_pts, s_pts, inds, xg)
+    assert out.dtype == (BF if bf else torch.float32)
+    mk = lambda c: types.SimpleNamespace(modules=lambda: [c], l1=torch.nn.L1Loss(), K=15, repulse_extent=1.2,
+                                         deform_fitting_power=1.0)
+    reg = p2p_fitting_regularizer(mk(conv))
+    ((out.float() * dy.float()).sum() + reg).backward()
+    torch.cuda.synchronize()
+    xc = x.float().cpu().requires_grad_(True)
+    with kpconv_ref.cpu_reference_mode():
+        ref = twin(q_pts.cpu(), s_pts.cpu(), inds.cpu(), xc)
+        reg_c = p2p_fitting_regularizer(mk(twin))
+    ((ref * dy.float().cpu()).sum() + reg_c).backward()
+    errs = {"offset_features": rel(conv.offset_features, twin.offset_features),
+            "deformed_KP": rel(conv.deformed_KP, twin.deformed_KP), "min_d2": rel(conv.min_d2, twin.min_d2),
+            "out": rel(out, ref), "reg": abs(float(reg) - float(reg_c)) / abs(float(reg_c)),
+            "dx_max": rel(xg.grad, xc.grad), "dx_l2": rel2(xg.grad, xc.grad),
+            "dW": rel(conv.weights.grad, twin.weights.grad),
+            "dW_off": rel(conv.offset_conv.weights.grad, twin.offset_conv.weights.grad),
+            "db_off": rel(conv.offset_bias.grad, twin.offset_bias.grad),
+            "dW_off_l2": rel2(conv.offset_conv.weights.grad, twin.offset_conv.weights.grad),
+            "db_off_l2": rel2(conv.offset_bias.grad, twin.offset_bias.grad), "h": h, "nq": int(q_pts.shape[0])}
+    _report("%s_l%d_c%d_%s" % (kind, lvl, ci, rows), errs)
+    if not bf:
+        for k in ("offset_features", "deformed_KP", "min_d2", "out", "dW"):
+            assert errs[k] < 1e-4, (k, errs)
+        assert errs["reg"] < 1e-5, errs
+        # gradients that flow through the learned offsets (d w / d kp jumps at the influence extent: 5e-4)
+        for k in ("dx_max", "dW_off", "db_off"):
+            assert errs[k] < 5e-4, (k, errs)
+    else:
+        assert errs["offset_features"] < 1e-2 and errs["deformed_KP"] < 1e-2 and errs["min_d2"] < 2e-2, errs
+        assert errs["out"] < 2e-2 and errs["reg"] < 2e-2, errs
+        # gradients through the learned offsets: d w / d kp jumps at the influence extent, so the bf16 rounding of the offsets
+        # flips boundary terms (tests/test_bf16_gpu.py header): 0.12 as ONE vector, single entries (sums over as few as
+        # 1 300 queries on the strided layers) within 0.30 of the tensor's maximum
+        assert errs["dx_l2"] < 0.12 and errs["dx_max"] < 0.30, errs
+        assert errs["dW"] < 3e-2 and errs["dW_off_l2"] < 0.12 and errs["db_off_l2"] < 0.12, errs
+        assert errs["dW_off"] < 0.30 and errs["db_off"] < 0.30, errs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full size
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("rows", ["bf16", "f32"])
+def test_full_size_config5_gather_is_adjoint_and_linear(gpu, rows):
+    """BASELINE config 5 at its FULL size (8 x 50 000 points, limits 422 / 519 / 472 / 193 / 34): with the per-query kernel
+    points and modulations held fixed, x -> wf is linear and the backward kernel must be its adjoint, <wf(x), g> = <x, dx(g)>,
+    on every level's self-query layer and on the strided layers of levels 0 and 1 (float64 inner products).  The
+    in-degree of a support reaches several hundred pairs here."""
+    from weasal_amd import config as wcfg, ops, pyramid, synthetic
+    from weasal_amd.kernel_points import load_kernels
+    cfg = wcfg.DALESDeformConfig()
+    wl = synthetic.WORKLOADS["dales_deform"]
+    pts, feats, labels, lens = synthetic.make_inputs(79, wl["spheres"], wl["points"], wl["radius"], cfg.in_features_dim)
+    np.random.seed(3)
+    batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu), torch.from_numpy(labels).to(gpu),
+                                lens, LIMITS)
+    batch.activate()
+    assert batch.points[0].shape[0] == 400000 and batch.neighbors[0].shape[1] == 422 and batch.neighbors[1].shape[1] == 519
+    dt = BF if rows == "bf16" else torch.float32
+    # both sides are sums of n random-sign terms of size |wf| |g| / n: an independent relative error e per element shows as
+    # e * |wf| |g| / sqrt(n) = e * scale.  f32: re-association, e ~ 1e-6; bf16: wf and dx rounded once each, e = 2^-9
+    tol = 2e-2 if rows == "bf16" else 2e-5
+    torch.manual_seed(5)
+    checked = 0
+    for lvl, ci in ((0, 32), (1, 64), (2, 128), (3, 256)):
+        r = cfg.first_subsampling_dl * cfg.conv_radius * 2 ** lvl
+        extent = r * cfg.KP_extent / cfg.conv_radius
+        kp = torch.from_numpy(load_kernels(r, 15, dimension=3, fixed="center").astype(np.float32)).to(gpu)
+        cases = [(batch.points[lvl], batch.points[lvl], batch.neighbors[lvl])]
+        if lvl < 2:
+            cases.append((batch.points[lvl + 1], batch.points[lvl], batch.pools[lvl]))
+        for q_pts, s_pts, inds in cases:
+            nq = q_pts.shape[0]
+            dkp = (kp.unsqueeze(0) + 0.15 * extent * torch.randn(nq, 15, 3, device=gpu)).contiguous()
+            mod = (2 * torch.sigmoid(torch.randn(nq, 15, device=gpu))).contiguous()
+            x = torch.randn(s_pts.shape[0], ci, device=gpu).to(dt).requires_grad_(True)
+            y = torch.randn(s_pts.shape[0], ci, device=gpu).to(dt)
+            wf, _ = ops.kpconv_gather(x, q_pts, s_pts, inds, kp, extent, deformed_kp=dkp, modulations=mod, want_min_d2=True)
+            g = torch.randn_like(wf)
+            dx, = torch.autograd.grad(wf, x, g)
+            lhs = float((wf.detach().double() * g.double()).sum())
+            rhs = float((x.detach().double() * dx.double()).sum())
+            scale = float(wf.detach().double().norm() * g.double().norm()) / wf.numel() ** 0.5
+            assert abs(lhs - rhs) <= tol * scale, (lvl, lhs, rhs, scale)
+            if rows == "f32":
+                wy, _ = ops.kpconv_gather(y, q_pts, s_pts, inds, kp, extent, deformed_kp=dkp, modulations=mod, want_min_d2=True)
+                wz, _ = ops.kpconv_gather(2.0 * x.detach() - 3.0 * y, q_pts, s_pts, inds, kp, extent, deformed_kp=dkp,
+                                          modulations=mod, want_min_d2=True)
+                refz = 2.0 * wf.detach() - 3.0 * wy
+                assert float((wz - refz).abs().max()) <= 2e-5 * float(refz.abs().max()), lvl
+            checked += 1
+            del wf, g, dx, x, y, dkp, mod
+    assert checked == 6
+    for _, grid in batch.search_grids:
+        assert int(grid.overflow.item()) == 0

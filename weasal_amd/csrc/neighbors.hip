@@ -378,6 +378,175 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
     if (max_count && lane == 0 && local_max > 0) atomicMax(max_count, local_max);
 }
 
+// Rows of 129 .. 1024 neighbours: the deformable radius of BASELINE config 5 (datasets/common.py:500-502: every level is
+// searched at 2 r, about 8 x the neighbours; calibrated limits 422 / 519 / 472).  Same candidate walk as nb_fill128; what
+// changes is the sort.  Rank by counting is quadratic (500 keys: 250 000 comparisons per query) and the bitonic network
+// of nb_fill_kernel<2048> runs 45 dependent LDS stages on a 64 KB slab (2 waves per SIMD): 4.2 ms per launch in round 2,
+// 55 ms per config-5 step.  Here the keys go through ONE level of buckets first:
+//   bucket(key) = min(NB - 1, (int)(d2 * NB / r^2))      -- monotone in d2 (a float multiply by a positive constant and
+//                                                           the conversion both are), equal d2 share a bucket
+//   rank(key)   = #keys in smaller buckets + #keys of the same bucket that are smaller
+// so the sorted position is still a pure function of the (distinct) keys -- the LDS atomics below only hand out arbitrary
+// slots INSIDE a bucket, which the final within-bucket count makes irrelevant: bit-identical rows from run to run.
+// With NB = 256 a 500-key row has ~2 keys per bucket (~8 in the fullest): the within-bucket count is a handful of LDS
+// reads per key, taken for all of a lane's keys together (independent chains).
+template <typename OutT>
+__global__ __launch_bounds__(256) void nb_fill_wide_kernel(const float* __restrict__ queries, int64_t nq,
+                                                           const CloudGrid* __restrict__ grids, int nb,
+                                                           const int32_t* __restrict__ cell_start,
+                                                           const float4* __restrict__ sorted, float r2, int64_t ns,
+                                                           int width, const int32_t* __restrict__ qorder, OutT* __restrict__ out,
+                                                           int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
+                                                           unsigned long long* __restrict__ key_last)
+{
+    constexpr int CAP = 1024, NB = 256, KPL = CAP / 64;
+    __shared__ unsigned long long slab_all[4][CAP + 64];      // keys in arrival order (+ one dummy slot per lane)
+    __shared__ unsigned short member_all[4][CAP];             // slab positions grouped by bucket
+    __shared__ int hist_all[4][NB];
+    __shared__ int start_all[4][NB];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    unsigned long long* slab = slab_all[wave];
+    unsigned short* member = member_all[wave];
+    int* hist = hist_all[wave];
+    int* start = start_all[wave];
+    const float bscale = (float)NB / r2;
+    auto wsync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    int local_max = 0;
+    int64_t ibeg, iend;
+    ws_block_range(nq, ibeg, iend);
+    int b = 0;
+    CloudGrid g = grids[0];
+    for (int64_t it = ibeg + wave; it < iend; it += 4) {
+        const int64_t q = qorder ? (int64_t)qorder[it] : it;
+        if (q < g.q_base || q >= g.q_base + g.q_len) {
+            b = find_cloud_q(grids, nb, q);
+            g = grids[b];
+        }
+        const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
+        int cnt = 0;
+        auto take = [&](const float4& c, bool active) {
+            const float d2 = ref_d2(qx, qy, qz, c);
+            const bool hit = active && d2 < r2;
+            const unsigned long long m = __ballot(hit);
+            const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            slab[(hit && pos < CAP) ? pos : CAP + lane] =
+                ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c.w);
+            cnt += __builtin_popcountll(m);
+        };
+        for (int i = lane; i < NB; i += 64) hist[i] = 0;
+        if (g.s_len > 0) {
+            const int cx = cell_coord(qx, g.lo[0], g.inv_cell);
+            const int cy = cell_coord(qy, g.lo[1], g.inv_cell);
+            const int cz = cell_coord(qz, g.lo[2], g.inv_cell);
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            int rb[9], re[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+                const bool ok = x0 <= x1 && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+                const int row = g.cell_base + ((ok ? z : 0) * g.ny + (ok ? y : 0)) * g.nx;
+                rb[r] = ok ? cell_start[row + x0] : 0;
+                re[r] = ok ? cell_start[row + x1 + 1] : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                // runs of a few hundred candidates: two batches of 64 in flight per iteration
+                for (int p0 = rb[r]; p0 < re[r]; p0 += 128) {
+                    const int pa = p0 + lane, pb = p0 + 64 + lane;
+                    const float4 ca = sorted[pa < re[r] ? pa : rb[r]];
+                    const float4 cb = sorted[pb < re[r] ? pb : rb[r]];
+                    take(ca, pa < re[r]);
+                    if (p0 + 64 < re[r]) take(cb, pb < re[r]);
+                }
+            }
+        }
+        if (counts) {
+            if (lane == 0) counts[q] = cnt;
+            local_max = max(local_max, cnt);
+        }
+        const int cntc = min(cnt, CAP);
+        wsync();
+        // ---- A: bucket of every key, slot inside the bucket from an LDS atomic
+        unsigned long long key[KPL];
+        int bk[KPL], pk[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            key[j] = ~0ull; bk[j] = 0; pk[j] = 0;
+            if (64 * j < cntc) {
+                const int i = lane + 64 * j;
+                if (i < cntc) {
+                    key[j] = slab[i];
+                    const float d2 = __uint_as_float((unsigned)(key[j] >> 32));
+                    bk[j] = min(NB - 1, (int)(d2 * bscale));
+                    pk[j] = atomicAdd(&hist[bk[j]], 1);
+                }
+            }
+        }
+        wsync();
+        // ---- B: exclusive scan of the histogram (lane owns 4 consecutive buckets), largest bucket
+        const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const int own = (h0 + h1) + (h2 + h3);
+        int incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            incl += lane >= o ? t : 0;
+        }
+        const int excl = incl - own;
+        start[4 * lane] = excl; start[4 * lane + 1] = excl + h0; start[4 * lane + 2] = excl + h0 + h1; start[4 * lane + 3] = excl + h0 + h1 + h2;
+        int maxb = max(max(h0, h1), max(h2, h3));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxb = max(maxb, __shfl_xor(maxb, o, 64));
+        maxb = __builtin_amdgcn_readfirstlane(maxb);
+        wsync();
+        // ---- C: slab positions grouped by bucket
+        int sb[KPL], nbk[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            sb[j] = 0; nbk[j] = 0;
+            if (64 * j < cntc) {
+                const int i = lane + 64 * j;
+                if (i < cntc) {
+                    sb[j] = start[bk[j]];
+                    nbk[j] = hist[bk[j]];
+                    member[sb[j] + pk[j]] = (unsigned short)i;
+                }
+            }
+        }
+        wsync();
+        // ---- D: sorted position = keys in smaller buckets + smaller keys of the own bucket
+        int rank[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) rank[j] = sb[j];
+        for (int t = 0; t < maxb; ++t) {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                if (64 * j < cntc) {
+                    const bool ok = t < nbk[j];
+                    const unsigned long long other = slab[member[ok ? sb[j] + t : 0]];
+                    rank[j] += (ok && other < key[j]) ? 1 : 0;
+                }
+            }
+        }
+        OutT* orow = out + q * width;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            if (64 * j < cntc) {
+                const int i = lane + 64 * j;
+                if (i < cntc && rank[j] < width) orow[rank[j]] = (OutT)(unsigned)(key[j] & 0xffffffffull);
+                if (key_last && cnt > width && i < cntc && rank[j] == width - 1) key_last[q] = key[j];
+            }
+        }
+        for (int j = cntc + lane; j < width; j += 64) orow[j] = (OutT)ns;
+        if (key_last && cnt <= width && lane == 0) key_last[q] = ~0ull;
+        wsync();
+    }
+    if (max_count && lane == 0 && local_max > 0) atomicMax(max_count, local_max);
+}
+
 __global__ __launch_bounds__(256) void nb_order_kernel(const float4* __restrict__ sorted, int64_t ns, int32_t* __restrict__ order)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ns; i += (int64_t)gridDim.x * 256)
@@ -593,7 +762,14 @@ static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* 
             nb_fill128_kernel<int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
                                                              ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx, kl);
     }
-    else if (cap <= 512) WS_NB_FILL(512);
+    else if (cap <= 1024) {
+        if (out_i32)
+            nb_fill_wide_kernel<int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
+                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i32, cn, mx, kl);
+        else
+            nb_fill_wide_kernel<int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
+                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx, kl);
+    }
     else if (cap <= 2048) WS_NB_FILL(2048);
     else return ws_fail(WS_ERR_UNSUPPORTED, "max neighbour count %d exceeds the 2048-entry sort slab", cap);
 #undef WS_NB_FILL
@@ -614,7 +790,7 @@ int ws_radius_neighbors_search(ws_neighbors_ws* ws, const float* queries, int64_
     hipStream_t st = (hipStream_t)stream;
     int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
     if (rc) { if (ws) ws->nq = 0; return rc; }
-    int cap = 128;
+    int cap = width > 128 ? 1024 : 128;      // wide rows are asked for: the bucketed sort from the start
     for (;;) {
         WS_HIP(hipMemsetAsync(ws->max_count_word, 0, sizeof(int32_t), st));
         if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st))) return rc;
@@ -641,9 +817,9 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, 
     hipStream_t st = (hipStream_t)stream;
     int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
     if (rc) { if (ws) ws->nq = 0; return rc; }
-    // rows wider than the 128-entry fast path are asked for (deformable radius): sort slab of 2048 entries from the start,
+    // rows wider than the 128-entry fast path are asked for (deformable radius): the 1024-key bucketed sort from the start,
     // instead of a 128-entry pass the caller would have to repeat
-    const int cap = width > 128 ? 2048 : 128;
+    const int cap = width > 128 ? 1024 : 128;
     if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st))) return rc;   // max-count word cleared by nb_prepare
     WS_HIP(hipMemcpyAsync(d_max_count, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     ws->max_count_host = cap;   // unknown on the host; rows beyond the slab are reported through d_max_count

@@ -803,7 +803,7 @@ class DeferredSearches:
             q, s, ql, sl, radius, width = args
             if mc == 0:
                 raise _lib.WeasalHipError("libweasal_hip status 4: Error")
-            if mc > (2048 if width > 128 else 128):      # beyond the sort slab the asynchronous pass used
+            if mc > (1024 if width > 128 else 128):      # beyond the sort slab the asynchronous pass used
                 out = radius_neighbors(q, s, ql, sl, radius, limit=width, dtype=torch.int64)
             elif mc < width:
                 out = out[:, :int(mc)].contiguous()
