@@ -531,6 +531,54 @@ int ws_softmax_ce_bwd(const float* logits, int64_t n, int32_t c, int64_t ldl, co
 int ws_sgd_step(float* const* h_params, const float* const* h_grads, float* const* h_bufs, const int64_t* h_sizes, int32_t count,
                 float lr, float momentum, float weight_decay, float clip_value, int32_t first, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Deformable KPConv, the fast path of BASELINE config 5 (models/blocks.py:244-325, 366-367 with KP_influence = 'linear',
+ * aggregation_mode = 'sum'; neighbour rows of several hundred columns: datasets/common.py:500-502).
+ *
+ * ws_kpconv_deform_prepare: blocks.py:250-267, 287-288 in one pass.  offset_features [n, od] f32 (od = 3k, or 4k when
+ *   modulated) -> deformed_kp [n,k,3] = offset * extent + kernel_points (two roundings, like the reference's mul and
+ *   add), modulations [n,k] = 2 sigmoid(last k columns) (NULL / ignored when not modulated), and kp4 [n,k] float4 =
+ *   (x, y, z, modulation or 1): the packed operand of the entries below (16-byte aligned).  deformed_kp may be NULL.
+ * ws_kpconv_deform_prepare_bwd: d offset_features [n, od] from d_kp4 [n,k,4] (NULL = zero) and / or a second gradient
+ *   d_deformed_kp [n,k,3] of the positions (NULL = none; the regulariser's).
+ * ws_kpconv_gather_fwd_def / _bwd_x_def / _bwd_geom_def: ws_kpconv_gather_fwd / _bwd_x / _bwd_geom for that mode with
+ *   kp4 in place of (kernel_points, deformed_kp, modulations).  The in-range filter of blocks.py:301-325 is implied: with
+ *   the linear influence a neighbour without a kernel point inside the extent has 15 zero influences.  _bwd_geom_def
+ *   (the dense product dwf[q] . x[neighbours]^T on the matrix core; ci % 16 == 0) writes d_kp4 [nq,k,4] =
+ *   (d x, d y, d z, d modulation), including the min_d2 path when d_min_d2 != NULL.  rows_bf16 != 0: the feature rows
+ *   x / wf / dwf / dx are bf16.
+ * ws_kpconv_gather_bwd_x_grid_wide: ws_kpconv_gather_bwd_x_grid for ANY in-degree (rows wider than 128 neighbours): the
+ *   candidate slab is a queue that is consumed 64 pairs at a time.  Rigid (kp4 NULL, kernel_points given) or deformable
+ *   (kp4); linear influence, sum aggregation.  rows / rows_h as in ws_kpconv_gather_bwd_x_grid_gated (NULL = walk the grid).
+ * ws_p2p_regularizer_fwd / _bwd: models/architectures.py:24-57 for ONE layer.  out2[0] = mean |min_d2 / extent^2|,
+ *   out2[1] = sum_i mean_n |sum_{j != i} min(|kp_i - kp_j| / extent - repulse_extent, 0)^2| / k (the other points
+ *   detached); positions from deformed_kp [n,k,3] or, when that is NULL, from kp4.  The backward takes g2 = (d loss /
+ *   d out2[0], d loss / d out2[1]) as DEVICE floats and writes d_min_d2 [n,k], d_deformed_kp [n,k,3].
+ *   scratch: ws_p2p_regularizer_scratch_bytes(n).
+ * ------------------------------------------------------------------------------------------ */
+int ws_kpconv_deform_prepare(const float* offset_features, int64_t n, int32_t od, const float* kernel_points, int32_t k,
+                             float extent, int32_t modulated, float* deformed_kp, float* modulations, float* kp4, void* stream);
+int ws_kpconv_deform_prepare_bwd(const float* d_kp4, const float* d_deformed_kp, const float* kp4, int64_t n, int32_t od, int32_t k,
+                                 float extent, int32_t modulated, float* d_offset_features, void* stream);
+int ws_kpconv_gather_fwd_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                             const void* x, int32_t ci, const float* kp4, int32_t k, float extent, const int32_t* order,
+                             void* wf, float* min_d2, int32_t rows_bf16, void* stream);
+int ws_kpconv_gather_bwd_x_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, int32_t h,
+                               const int32_t* t_offsets, const int32_t* t_pairs, const void* dwf, int32_t ci, const float* kp4,
+                               int32_t k, float extent, const int32_t* order, void* dx, int32_t rows_bf16, void* stream);
+int ws_kpconv_gather_bwd_x_grid_wide(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                     const uint64_t* key_last, float radius, const void* dwf, int32_t ci,
+                                     const float* kernel_points, int32_t k, const float* kp4, float extent, const int32_t* order,
+                                     const int64_t* rows, int32_t rows_h, void* dx, int32_t rows_bf16, void* stream);
+int ws_kpconv_gather_bwd_geom_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                                  const void* x, int32_t ci, const void* dwf, const float* kp4, int32_t k, const float* d_min_d2,
+                                  float extent, const int32_t* order, float* d_kp4, int32_t rows_bf16, void* stream);
+int64_t ws_p2p_regularizer_scratch_bytes(int64_t n);
+int ws_p2p_regularizer_fwd(const float* deformed_kp, const float* kp4, const float* min_d2, int64_t n, int32_t k, float extent,
+                           float repulse_extent, float* out2, void* scratch, void* stream);
+int ws_p2p_regularizer_bwd(const float* deformed_kp, const float* kp4, const float* min_d2, int64_t n, int32_t k, float extent,
+                           float repulse_extent, const float* g2, float* d_min_d2, float* d_deformed_kp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

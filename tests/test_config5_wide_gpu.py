@@ -192,7 +192,7 @@ def test_deformable_kpconv_real_width_vs_oracle(gpu, kind, lvl, ci, rows):
         q_pts, s_pts, inds = batch.points[lvl + 1], batch.points[lvl], batch.pools[lvl]
     h = inds.shape[1]
     assert h == min(LIMITS[lvl], h) and (lvl > 1 or h == LIMITS[lvl]), (lvl, h)
-    if kind == "self" and ops.GRID_BACKWARD and lvl < 2 and os.environ.get("WEASAL_EXPECT_WIDE_GRID", "1") != "0":
+    if kind == "self" and ops.GRID_BACKWARD and lvl < 2:
         assert ops._grid_for(inds) is not None, "the wide self-query layer must take the table-free backward"
     conv, twin = _layer_pair(gpu, ci, ci, extent, r, bf)
     torch.manual_seed(4 + lvl)
@@ -205,18 +205,47 @@ def test_deformable_kpconv_real_width_vs_oracle(gpu, kind, lvl, ci, rows):
     assert out.dtype == (BF if bf else torch.float32)
     mk = lambda c: types.SimpleNamespace(modules=lambda: [c], l1=torch.nn.L1Loss(), K=15, repulse_extent=1.2,
                                          deform_fitting_power=1.0)
+    got = {}
+    conv.offset_features.register_hook(lambda g_: got.__setitem__("d_off", g_.detach().float().cpu()))
     reg = p2p_fitting_regularizer(mk(conv))
     ((out.float() * dy.float()).sum() + reg).backward()
     torch.cuda.synchronize()
     xc = x.float().cpu().requires_grad_(True)
+    want = {}
     with kpconv_ref.cpu_reference_mode():
         ref = twin(q_pts.cpu(), s_pts.cpu(), inds.cpu(), xc)
+        twin.offset_features.register_hook(lambda g_: want.__setitem__("d_off", g_.detach()))
         reg_c = p2p_fitting_regularizer(mk(twin))
     ((ref * dy.float().cpu()).sum() + reg_c).backward()
+    # ---- where the reference's own gradient is discontinuous within float rounding.  d w / d kp of the linear influence
+    # jumps from (n - kp) / (extent |n - kp|) to 0 at |n - kp| = extent (models/blocks.py:337): a (neighbour, kernel point)
+    # pair within a few ulps of that boundary is counted by one fp32 evaluation order and not by another -- among the
+    # ~4e7 pairs of a 7 000 x 422 x 15 layer a handful always is.  Those query rows are identified on the ORACLE's side
+    # (distance within 2e-6 relative of the extent) and are the only rows allowed to differ; everything downstream of
+    # them (the offset convolution's weight gradient, the rows of dx they scatter to) is compared without them.
+    with torch.no_grad():
+        s_pad = torch.cat((s_pts.cpu(), torch.zeros(1, 3) + 1e6), 0)
+        near = torch.zeros(q_pts.shape[0], dtype=torch.bool)
+        qc, ic, kc = q_pts.cpu(), inds.cpu(), twin.deformed_KP.detach()
+        for a in range(0, qc.shape[0], 512):
+            nb_ = s_pad[ic[a:a + 512]] - qc[a:a + 512].unsqueeze(1)                           # [n, H, 3]
+            d_ = torch.sqrt(((nb_.unsqueeze(2) - kc[a:a + 512].unsqueeze(1)) ** 2).sum(3))   # [n, H, K]
+            near[a:a + 512] = ((d_ / extent - 1).abs() < 2e-6).flatten(1).any(1)
+    d_scale = float(want["d_off"].abs().max())
+    row_err = (got["d_off"] - want["d_off"]).abs().amax(dim=1) / d_scale
+    bad = row_err > (5e-4 if not bf else 1.0)
+    assert int((bad & ~near).sum()) == 0, "rows of d offset_features differ where the reference's gradient is continuous"
+    assert int(bad.sum()) <= 8, int(bad.sum())
+    clean_q = ~bad
+    touched = torch.zeros(s_pts.shape[0] + 1, dtype=torch.bool)
+    touched[ic[bad].flatten()] = True                                                         # supports the flipped rows scatter to
+    clean_s = ~touched[:-1]
+    sel = lambda t, m: t.detach().float().cpu()[m]
     errs = {"offset_features": rel(conv.offset_features, twin.offset_features),
             "deformed_KP": rel(conv.deformed_KP, twin.deformed_KP), "min_d2": rel(conv.min_d2, twin.min_d2),
-            "out": rel(out, ref), "reg": abs(float(reg) - float(reg_c)) / abs(float(reg_c)),
-            "dx_max": rel(xg.grad, xc.grad), "dx_l2": rel2(xg.grad, xc.grad),
+            "out": rel(out, ref), "reg": abs(float(reg.detach()) - float(reg_c.detach())) / abs(float(reg_c.detach())),
+            "d_off_rows": float(row_err[clean_q].max()), "boundary_rows": int(near.sum()), "flipped_rows": int(bad.sum()),
+            "dx_max": rel(sel(xg.grad, clean_s), sel(xc.grad, clean_s)), "dx_l2": rel2(sel(xg.grad, clean_s), sel(xc.grad, clean_s)),
             "dW": rel(conv.weights.grad, twin.weights.grad),
             "dW_off": rel(conv.offset_conv.weights.grad, twin.offset_conv.weights.grad),
             "db_off": rel(conv.offset_bias.grad, twin.offset_bias.grad),
@@ -227,9 +256,12 @@ def test_deformable_kpconv_real_width_vs_oracle(gpu, kind, lvl, ci, rows):
         for k in ("offset_features", "deformed_KP", "min_d2", "out", "dW"):
             assert errs[k] < 1e-4, (k, errs)
         assert errs["reg"] < 1e-5, errs
-        # gradients that flow through the learned offsets (d w / d kp jumps at the influence extent: 5e-4)
-        for k in ("dx_max", "dW_off", "db_off"):
-            assert errs[k] < 5e-4, (k, errs)
+        # gradients that flow through the learned offsets: 5e-4 wherever no boundary pair flipped
+        assert errs["d_off_rows"] < 5e-4 and errs["dx_max"] < 5e-4, errs
+        if errs["flipped_rows"] == 0:
+            assert errs["dW_off"] < 5e-4 and errs["db_off"] < 5e-4, errs
+        else:       # sums over all rows: the flipped rows' (legitimately different) terms are in them
+            assert errs["dW_off_l2"] < 2e-2 and errs["db_off_l2"] < 2e-2, errs
     else:
         assert errs["offset_features"] < 1e-2 and errs["deformed_KP"] < 1e-2 and errs["min_d2"] < 2e-2, errs
         assert errs["out"] < 2e-2 and errs["reg"] < 2e-2, errs

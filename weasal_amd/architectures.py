@@ -9,6 +9,8 @@ without ``.cuda()`` calls (**parity unpinned**: tor
 reference function has never run here -- it is checked against oracle/contrast_ref.py only).  The weak-label
 ``KPFCNN_mprm`` (architectures.py:507-807, rank 3) is at the end of this file, pinned by golden g10.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -17,6 +19,7 @@ from . import fused, ops
 from .blocks import KPConv, NearestUpsampleBlock, UnaryBlock, block_decider, closest_pool
 
 _LAYER_CHANGE = ('pool', 'strided', 'upsample', 'global')
+REGULARIZER_KERNEL = os.environ.get("WEASAL_REG_KERNEL", "1") != "0"      # A/B switch: 0 = the torch-op form below
 
 
 def p2p_fitting_regularizer(net):
@@ -29,6 +32,12 @@ def p2p_fitting_regularizer(net):
         layers = [m for m in net.modules() if isinstance(m, KPConv) and m.deformable]
         net._deformable_layers = layers
     for m in layers:
+        if REGULARIZER_KERNEL and m.min_d2.is_cuda and net.K == 15 and ops.kpconv_gather is ops._KPCONV_GATHER_SELF:
+            # both terms and their gradients in one kernel each way (ws_p2p_regularizer_fwd / _bwd)
+            fr = ops.p2p_regularizer(m.deformed_KP, m.min_d2, m.KP_extent, net.repulse_extent)
+            fitting_loss = fitting_loss + fr[0]
+            repulsive_loss = repulsive_loss + fr[1]
+            continue
         kp_min_d2 = m.min_d2 / (m.KP_extent ** 2)
         fitting_loss = fitting_loss + net.l1(kp_min_d2, torch.zeros_like(kp_min_d2))
         locs = m.deformed_KP / m.KP_extent                                   # [N, K, 3]

@@ -17,6 +17,7 @@ Quirks of the reference that are preserved on purpose:
     feature row (blocks.py:278,357); max_pool includes that zero row (blocks.py:104).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -25,6 +26,8 @@ from torch.nn.parameter import Parameter
 
 from . import fused, ops
 from .kernel_points import load_kernels
+
+DEFORM_FAST_PATH = os.environ.get("WEASAL_DEFORM_FAST", "1") != "0"      # A/B switch (diagnostics, tests): 0 = generic kernels
 
 
 # ---------------------------------------------------------------------------------------------
@@ -123,6 +126,16 @@ class KPConv(nn.Module):
 
         deformed = None
         modulations = None
+        if self.deformable and DEFORM_FAST_PATH and ops.deform_fast_path_ok(x, self.K, self.KP_influence, self.aggregation_mode):
+            # BASELINE config 5's mode (linear influence, sum): offsets, modulations and kernel points in one pass
+            # (ws_kpconv_deform_prepare), per-query kernel points packed for the gather kernels; the offset bias rides on
+            # the epilogue of the offset convolution's contraction
+            self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x, _bias=self.offset_bias, _out_f32=True)
+            kp4, self.deformed_KP, _ = ops.deform_prepare(self.offset_features, self.kernel_points, self.KP_extent, self.modulated)
+            wf, self.min_d2 = ops.kpconv_gather_def(x, kp4, q_pts, s_pts, neighb_inds, self.KP_extent)
+            return ops.matmul_epilogue(wf.reshape(wf.shape[0], -1),
+                                       self.weights.reshape(self.K * self.in_channels, self.out_channels),
+                                       bias=_bias, slope=_slope, out_f32=_out_f32)
         if self.deformable:
             # offsets from a rigid KPConv on the same neighbourhood (blocks.py:244-267)
             self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x, _out_f32=True) + self.offset_bias

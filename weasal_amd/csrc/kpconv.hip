@@ -31,6 +31,9 @@ struct GeomParams {
     int rows_h;           // none).  A support whose own row was not truncated (key_last[s] = "infinity") holds every
                           // point within the radius in that row -- a superset of the queries that kept s -- so its
                           // candidates are the row's entries instead of the 27-cell walk.
+    const float4* kp4;    // MODE 2 only (deformable / modulated, linear influence, sum): the per-query kernel points packed as
+                          // [nq, 15] float4 = (x, y, z, modulation) -- ONE aligned 16-byte load per (query, kernel point)
+                          // where the reference-shaped operands deformed_kp [nq,15,3] + modulations [nq,15] need four.
 };
 
 // Influence of the K kernel points on one neighbour offset n = s - q.  kp is wave-uniform.
@@ -251,6 +254,38 @@ __device__ __forceinline__ void kp_list2(float ax, float ay, float az, bool aliv
         segs[k] = total;
         total += ca + cb;
         maxlen = max(maxlen, ca + cb);
+    }
+    segs[K] = total;
+}
+
+// List phase of the deformable fast path (MODE 2: per-query kernel points + modulations, linear influence, sum
+// aggregation; models/blocks.py:244-267, 287-291, 330-346, 366-367).  lane = pair; `kq` = the 15 packed kernel points
+// (x, y, z, modulation) of the pair's QUERY: 15 independent 16-byte loads, all issued before the first use.  One pass:
+// the in-range filter of blocks.py:301-325 is implied by the linear influence (a neighbour with no kernel point inside
+// the extent has 15 zero influences), and the modulation multiplies the weight (d wf / d x = mod * w).
+template <int K>
+__device__ __forceinline__ void kp_list_def(float nx, float ny, float nz, bool live, const float4* __restrict__ kq,
+                                            float inv_extent, unsigned row_base, uint2* pool, int* segs, int lane, int& total,
+                                            int& maxlen)
+{
+    const unsigned dummy = POOL + 8 + lane;
+    float4 kp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) kp[k] = kq[k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float dx = nx - kp[k].x, dy = ny - kp[k].y, dz = nz - kp[k].z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        float w = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d) * inv_extent, 0.0f) * kp[k].w;
+        w = live ? w : 0.0f;
+        const unsigned long long m = __ballot(w != 0.0f);
+        const unsigned pos = (unsigned)(total + lane_rank(m));
+        const bool ok = (w != 0.0f) && pos < (unsigned)POOL;
+        pool[ok ? pos : dummy] = make_uint2(row_base + (unsigned)k, __float_as_uint(w));
+        segs[k] = total;
+        const int c = __builtin_popcountll(m);
+        total += c;
+        maxlen = max(maxlen, c);
     }
     segs[K] = total;
 }
@@ -577,7 +612,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     // fewer = fewer registers = more waves per SIMD.  The kernel is bound by instruction latency x occupancy (with every
     // memory access ablated it still takes 0.53 of its 0.68 ms on the 400k x 59 x 32 layer), so registers win
     constexpr int GS = GSV > 0 ? GSV : (NT <= 2 ? WS_K3_GS : (NT == 4 ? 2 : 1));
-    static_assert(!(DEF && MODE == 0), "deformable layers use MODE 1");
+    static_assert(!(DEF && MODE == 0), "deformable layers use MODE 1 or 2");
+    static_assert(MODE != 2 || DEF, "MODE 2 is the deformable fast path");
     static_assert(VECROW || NT == 1, "masked rows use one channel per lane");
     __shared__ float4 nb_all[4][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -593,7 +629,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
 
     float kx = 0.f, ky = 0.f, kz = 0.f;
     if (!DEF && haskp) { kx = kernel_points[3 * i]; ky = kernel_points[3 * i + 1]; kz = kernel_points[3 * i + 2]; }
-    if (MODE == 0 && !haskp) kx = ky = kz = 1.0e9f;               // the 16th "kernel point": far from everything, weight 0
+    if ((MODE == 0 || MODE == 2) && !haskp) kx = ky = kz = 1.0e9f;   // the 16th "kernel point": far from everything, weight 0
+    float kmod = 0.0f;                                            // MODE 2: modulation of this lane's kernel point
 
     // ---- software pipeline over the items of this wave.  Everything an item needs before its row loads -- its query index
     // (order[]), its index row, the neighbours' coordinates, its own coordinates -- is a chain of dependent memory
@@ -651,7 +688,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
         float q2x, q2y, q2z, p1x, p1y, p1z;
         q_xyz(qv2, q2x, q2y, q2z);
         pt_raw(idx1, p1x, p1y, p1z);
-        if (DEF && haskp) {
+        if constexpr (MODE == 2) {
+            if (haskp) {
+                const float4 kq = g.kp4[q * K + i];
+                kx = kq.x; ky = kq.y; kz = kq.z; kmod = kq.w;
+            }
+        } else if (DEF && haskp) {
             const float* kp = deformed_kp + q * (3 * K) + 3 * i;
             kx = kp[0]; ky = kp[1]; kz = kp[2];
         }
@@ -670,7 +712,14 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                     load_pt(idx, px, py, pz);
                 }
                 wave_lds_order();                                 // the previous chunk's readers are done
-                if constexpr (MODE == 0) {
+                if constexpr (MODE == 0 || MODE == 2) {
+                    // ---- MODE 2 (deformable + modulated, linear, sum; BASELINE config 5) shares this form: the lane's kernel
+                    // point is re-loaded per query (one float4 with its modulation), the modulation multiplies the influence
+                    // (A operand) instead of the finished row, min_d2 is tracked per lane.  The in-range filter of
+                    // blocks.py:301-325 needs no code here: with the linear influence a neighbour without a kernel point
+                    // inside the extent has all 15 influences equal to zero already.  Columns past the row are staged
+                    // far beyond the shadow point so that they never win the minimum; shadow columns take part in it with
+                    // the reference's coordinates (1e6 - q, blocks.py:278-284).
                     // ---- rigid / linear / sum: the instruction-lean form.  This kernel is bound by vector-instruction issue
                     // (SQ counters: the SIMDs issue ~88 % of the time, 435 VALU per query in the first form), so everything
                     // that can be decided once per neighbour is decided by the lane that stages it, not by the 16 lanes that
@@ -684,7 +733,11 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                     float* nbf = reinterpret_cast<float*>(nb);       // [pair p = 0..7][kk = 0..3][8 floats]
                     {
                         const bool real = idx >= 0 && (h0 + lane < h);
-                        const float sx = real ? px - qx : WS_SHADOW, sy = real ? py - qy : WS_SHADOW, sz = real ? pz - qz : WS_SHADOW;
+                        float sx = real ? px - qx : WS_SHADOW, sy = real ? py - qy : WS_SHADOW, sz = real ? pz - qz : WS_SHADOW;
+                        if constexpr (MODE == 2) {
+                            const bool incol = h0 + lane < h;
+                            sx = incol ? px - qx : 3.0e18f; sy = incol ? py - qy : 3.0e18f; sz = incol ? pz - qz : 3.0e18f;
+                        }
                         const unsigned off = real && !(g.ablate & 2) ? (unsigned)idx * (unsigned)ci : 0u;
                         const int sstep = lane >> 2, skk = lane & 3;  // this lane's neighbour is column 4 sstep + skk
                         float* dst = nbf + (((sstep >> 1) * 4 + skk) * 8) + (sstep & 1);
@@ -718,6 +771,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                             const f2 sd = f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
                             const f2 w = 1.0f - sd * inv_extent;
                             wb2[slot][u] = f2{fmaxf(w.x, 0.0f), fmaxf(w.y, 0.0f)};
+                            if constexpr (MODE == 2) {
+                                wb2[slot][u] = wb2[slot][u] * kmod;
+                                mind = fminf(mind, fminf(d2.x, d2.y));
+                            }
                         }
                     };
                     auto comp_pairs = [&](int slot) {
@@ -954,14 +1011,29 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
                 auto kp = [&](int k, int c) { return MODE == 0 ? kpr[MODE == 0 ? 3 * k + c : 0] : lkp[3 * k + c]; };
                 auto nomin = [&](int, float) {};
                 int total = 0, maxlen = 0;
-                kp_list<K, MODE>(nx, ny, nz, real, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod, pool, segs, lane, total,
+                if constexpr (MODE == 2) {
+                    const float4* kq = g.kp4 + (int64_t)q * K;
+                    kp_list_def<K>(nx, ny, nz, real, kq, inv_extent, (unsigned)(q * K), pool, segs, lane, total, maxlen);
+                    if (total <= POOL) {
+                        flush(total);
+                    } else {
+                        for (int sub = 0; sub < 4; ++sub) {
+                            total = 0; maxlen = 0;
+                            kp_list_def<K>(nx, ny, nz, real && (lane >> 4) == sub, kq, inv_extent, (unsigned)(q * K), pool, segs, lane,
+                                           total, maxlen);
+                            flush(total);
+                        }
+                    }
+                    continue;
+                }
+                kp_list<K, MODE == 2 ? 1 : MODE>(nx, ny, nz, real, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod, pool, segs, lane, total,
                                  maxlen, nomin);
                 if (total <= POOL) {
                     flush(total);
                 } else {
                     for (int sub = 0; sub < 4; ++sub) {
                         total = 0; maxlen = 0;
-                        kp_list<K, MODE>(nx, ny, nz, real && (lane >> 4) == sub, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod,
+                        kp_list<K, MODE == 2 ? 1 : MODE>(nx, ny, nz, real && (lane >> 4) == sub, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod,
                                          pool, segs, lane, total, maxlen, nomin);
                         flush(total);
                     }
@@ -1110,6 +1182,179 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_kernel(
                 d_kp[(q * K + k) * 3 + 1] = gy;
                 d_kp[(q * K + k) * 3 + 2] = gz;
                 if (d_mod) d_mod[q * K + k] = gmod;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 on the matrix core (deformable fast path: linear influence, sum aggregation, packed kernel points).
+// What the geometry backward needs per (query, neighbour h, kernel point k) is the scalar
+//     dot[k][h] = sum_c dwf[q,k,c] * x[inds[q,h], c]
+// -- per query a dense product  dWF_q (15 x Ci) . X_q^T (Ci x H).  The VALU form above evaluates it only where the
+// influence is live, one serial Ci-long chain per lane over two scattered rows (24 ms per config-5 level-0 launch).
+// Here it runs as v_mfma_f32_16x16x4_f32 over blocks of 16 neighbours:
+//   A  lane (i = lane&15, kk = lane>>4): CK = Ci/4 consecutive channels kk*CK .. of dwf[q, i, :], in registers for the
+//      whole query (Ci <= 128; wider rows re-load A per block: those levels hold a few hundred points);
+//   B  lane (j = lane&15, kk): the same channels of x[inds[q, 16 b + j], :]  (16 .. 64 contiguous bytes per lane);
+//   D  lane (j, g = lane>>4) ends with dot[4g + r][16 b + j], r = 0..3 -- exactly the (neighbour, kernel point) pairs
+//      whose geometry that lane then evaluates: influence, d influence / d kernel point, running arg-min of d2.
+// Per query: reduce the 4 x (3 + 1) sums over the 16 lanes of a group, add the min_d2 path at the arg-min column,
+// one float4 store (d x, d y, d z, d modulation) per kernel point.  Sums are per-lane partial sums combined by a fixed
+// shuffle tree: deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int CK, bool AREG, typename T>
+__global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_def_kernel(
+    const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
+    const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci, const T* __restrict__ dwf,
+    const float4* __restrict__ kp4, const float* __restrict__ d_min_d2, float extent, float4* __restrict__ d_kp4,
+    const int32_t* __restrict__ order)
+{
+    constexpr int K = 15;
+    constexpr int CB = 4 * CK;                                   // channels per pass of the product
+    __shared__ float4 nb_all[4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;                       // (= i, kk of the A / B operands)
+    float4* nb = nb_all[wave];
+    const float inv_extent = 1.0f / extent;
+    int64_t ibeg, iend;
+    ws_block_range(nq, ibeg, iend);
+    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+        const int64_t q = order ? (int64_t)order[item] : item;
+        float4 kq[4];
+        float cm[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g + r;
+            kq[r] = k < K ? kp4[q * K + k] : make_float4(1.0e9f, 1.0e9f, 1.0e9f, 0.0f);
+            cm[r] = kq[r].w * inv_extent;
+        }
+        const float qx = q_pts[3 * q + 0], qy = q_pts[3 * q + 1], qz = q_pts[3 * q + 2];
+        float a[CK];
+        auto load_a = [&](int cb) {
+            RowLoad<CK, T>::ld(dwf + (q * K + (j < K ? j : 0)) * ci + cb + g * CK, a);
+            if (j >= K) {
+#pragma unroll
+                for (int t = 0; t < CK; ++t) a[t] = 0.0f;
+            }
+        };
+        if (AREG) load_a(0);
+        float gk[4][3], gm[4], best[4];
+        int bestcol[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gk[r][0] = gk[r][1] = gk[r][2] = 0.0f;
+            gm[r] = 0.0f;
+            best[r] = 3.4e38f;
+            bestcol[r] = 0x7fffffff;
+        }
+        // index / coordinates of the first 64 columns
+        auto fetch = [&](int h0, int& idx, float& px, float& py, float& pz) {
+            const int col = h0 + lane;
+            idx = -1;
+            if (col < h) { const int64_t v = inds[q * h + col]; idx = (v >= 0 && v < ns) ? (int)v : -1; }
+            px = py = pz = WS_SHADOW;
+            if (idx >= 0) { px = s_pts[3 * (int64_t)idx]; py = s_pts[3 * (int64_t)idx + 1]; pz = s_pts[3 * (int64_t)idx + 2]; }
+        };
+        int idx; float px, py, pz;
+        fetch(0, idx, px, py, pz);
+        for (int h0 = 0; h0 < h; h0 += 64) {
+            wave_lds_order();                                     // the previous chunk's readers are done
+            {
+                const bool incol = h0 + lane < h;                 // past the row: far beyond the shadow point (never the minimum)
+                nb[lane] = make_float4(incol ? px - qx : 3.0e18f, incol ? py - qy : 3.0e18f, incol ? pz - qz : 3.0e18f,
+                                       __int_as_float(idx));
+            }
+            wave_lds_order();
+            if (h0 + 64 < h) fetch(h0 + 64, idx, px, py, pz);     // next chunk's chain under this chunk's work
+            const int nblk = min(4, (h - h0 + 15) >> 4);
+            float bv[2][CK];
+            float4 nv[2];
+            auto load_b = [&](int b4, int slot) {
+                nv[slot] = nb[16 * b4 + j];
+                if (AREG) {
+                    const int nidx = __float_as_int(nv[slot].w);
+                    RowLoad<CK, T>::ld(x + (size_t)((unsigned)(nidx >= 0 ? nidx : 0) * (unsigned)ci) + g * CK, bv[slot]);
+                }
+            };
+            auto compute = [&](int b4, int slot) {
+                f32x4v acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+                const float4 n = nv[slot];
+                if (AREG) {
+#pragma unroll
+                    for (int t = 0; t < CK; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bv[slot][t], acc, 0, 0, 0);
+                } else {
+                    const int nidx = __float_as_int(n.w);
+                    const T* xr = x + (size_t)((unsigned)(nidx >= 0 ? nidx : 0) * (unsigned)ci) + g * CK;
+                    for (int cb = 0; cb < ci; cb += CB) {
+                        load_a(cb);
+                        float bb[CK];
+                        RowLoad<CK, T>::ld(xr + cb, bb);
+#pragma unroll
+                        for (int t = 0; t < CK; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bb[t], acc, 0, 0, 0);
+                    }
+                }
+                const int col = h0 + 16 * b4 + j;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dx = n.x - kq[r].x, dy = n.y - kq[r].y, dz = n.z - kq[r].z;
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    const float rs = __builtin_amdgcn_rsqf(d2);
+                    const bool nz = d2 > 0.0f;
+                    const float sd = nz ? d2 * rs : 0.0f;
+                    const float t = 1.0f - sd * inv_extent;
+                    const float w = fmaxf(t, 0.0f);
+                    const float dot = acc[r];
+                    gm[r] = fmaf(w, dot, gm[r]);
+                    // w = 1 - |n - kp| / extent  ->  d w / d kp = (n - kp) / (extent |n - kp|), where 0 < w
+                    const float coef = (t > 0.0f && nz) ? dot * cm[r] * rs : 0.0f;
+                    gk[r][0] = fmaf(coef, dx, gk[r][0]);
+                    gk[r][1] = fmaf(coef, dy, gk[r][1]);
+                    gk[r][2] = fmaf(coef, dz, gk[r][2]);
+                    const bool lower = d2 < best[r];               // columns ascend per lane: the first minimum stays
+                    best[r] = lower ? d2 : best[r];
+                    bestcol[r] = lower ? col : bestcol[r];
+                }
+            };
+            load_b(0, 0);
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                if (b4 < nblk) {
+                    if (b4 + 1 < nblk) load_b(b4 + 1, (b4 + 1) & 1);
+                    compute(b4, b4 & 1);
+                }
+            }
+        }
+        // ---- per kernel point: sums over the 16 lanes of the group, arg-min of d2 (first column wins ties)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                gk[r][0] += __shfl_xor(gk[r][0], o, 64);
+                gk[r][1] += __shfl_xor(gk[r][1], o, 64);
+                gk[r][2] += __shfl_xor(gk[r][2], o, 64);
+                gm[r] += __shfl_xor(gm[r], o, 64);
+                const float ob = __shfl_xor(best[r], o, 64);
+                const int oc = __shfl_xor(bestcol[r], o, 64);
+                const bool take = ob < best[r] || (ob == best[r] && oc < bestcol[r]);
+                best[r] = take ? ob : best[r];
+                bestcol[r] = take ? oc : bestcol[r];
+            }
+            const int k = 4 * g + r;
+            if (k < K) {
+                float gx = gk[r][0], gy = gk[r][1], gz = gk[r][2];
+                if (d_min_d2) {
+                    // d min_d2[q,k] / d kp = 2 (kp - n) at the arg-min column (shadow columns take part, blocks.py:278-304)
+                    const int64_t v = inds[q * h + min(bestcol[r], h - 1)];
+                    float mx = WS_SHADOW, my = WS_SHADOW, mz = WS_SHADOW;
+                    if (v >= 0 && v < ns) { mx = s_pts[3 * v]; my = s_pts[3 * v + 1]; mz = s_pts[3 * v + 2]; }
+                    const float gmin = 2.0f * d_min_d2[q * K + k];
+                    gx = fmaf(gmin, kq[r].x - (mx - qx), gx);
+                    gy = fmaf(gmin, kq[r].y - (my - qy), gy);
+                    gz = fmaf(gmin, kq[r].z - (mz - qz), gz);
+                }
+                if (j == 0) d_kp4[q * K + k] = make_float4(gx, gy, gz, gm[r]);
             }
         }
     }
@@ -1384,6 +1629,251 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// K4G for wide rows: in-degrees of several hundred pairs per support (the deformable radius of BASELINE config 5:
+// limits 422 / 519 / 472).  Same membership test as kpconv_gather_bwd_x_grid_kernel; what changes:
+//   * the slab is a QUEUE, not a bound: whenever it holds 64 candidates more than one list phase consumes, the full
+//     64-entry batches are run through the list / flush phases and the remainder moves to the front -- any in-degree,
+//     no capacity flag, every list phase but the last on 64 live lanes;
+//   * accumulators for up to NCH channel chunks live in registers, so the candidates are walked ONCE per support
+//     whatever the row width (one pass for ci <= 4 G NCH = 256 channels);
+//   * the candidate runs are walked by a rolled loop (run bounds in LDS): with ~300 candidates per run the first-batch
+//     prefetch of the narrow kernel buys nothing and its nine-fold unrolled body would be inlined around every drain;
+//   * MODE 2: the deformable fast path (kp_list_def).
+// Summation order = order of the walk (a function of the grid alone): deterministic, equal to the transposed-table
+// form up to fp32 re-association.
+// ---------------------------------------------------------------------------------------------
+template <int K, int G, int MODE, bool VEC, typename T = float>
+__global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
+    const float* __restrict__ s_pts, int64_t ns, const CloudGrid* __restrict__ grids, int nb,
+    const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+    const unsigned long long* __restrict__ key_last, float r2, const T* __restrict__ dwf, int ci,
+    const float* __restrict__ kernel_points, const float* __restrict__ deformed_kp, const float* __restrict__ modulations,
+    GeomParams g, T* __restrict__ dx, const int32_t* __restrict__ order)
+{
+    constexpr int CC = 4 * G;
+    constexpr int S = 64 / G;
+    constexpr int NCH = 4;
+    constexpr int SLAB = 192;
+    __shared__ uint2 pool_all[4][POOL_ALLOC];
+    __shared__ int segs_all[4][K + 1];
+    __shared__ float4 slab_all[4][SLAB + 64];      // + one dummy slot per lane (unconditional writes)
+    __shared__ int2 runs_all[4][16];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    uint2* pool = pool_all[wave];
+    int* segs = segs_all[wave];
+    float4* slab = slab_all[wave];
+    int2* runs = runs_all[wave];
+    const int j = lane % G;
+    const int slot = lane / G;
+    const float inv_extent = 1.0f / g.extent;
+
+    float kpr[MODE == 0 ? 3 * K : 1];
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 3 * K; ++t) kpr[t] = kernel_points[t];
+    }
+
+    int64_t ibeg, iend;
+    ws_block_range(ns, ibeg, iend);
+    CloudGrid gr = grids[0];
+    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+        const int64_t s = order ? (int64_t)order[item] : item;
+        if (s < gr.s_base || s >= gr.s_base + gr.s_len) {
+            int b = 0;
+            while (b + 1 < nb && s >= grids[b].s_base + grids[b].s_len) ++b;
+            gr = grids[b];
+        }
+        const float sx = s_pts[3 * s + 0], sy = s_pts[3 * s + 1], sz = s_pts[3 * s + 2];
+        const bool from_row = g.rows != nullptr && key_last[s] == ~0ull;
+        for (int cg0 = 0; cg0 < ci; cg0 += NCH * CC) {
+            float4 acc[NCH];
+            float4 gq[NCH];
+            bool chok[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                gq[c] = make_float4(1.f, 1.f, 1.f, 1.f);
+                const int ch = cg0 + c * CC + 4 * j;
+                chok[c] = VEC ? (ch + 3 < ci) : (ch < ci);
+                if (g.gate && slot == 0 && ch < ci) {
+                    const T* gy = reinterpret_cast<const T*>(g.gate) + s * ci + ch;
+                    if (VEC) {
+                        if (chok[c]) gq[c] = ld4(gy);
+                    } else {
+                        if (ch + 0 < ci) gq[c].x = ld1(gy + 0);
+                        if (ch + 1 < ci) gq[c].y = ld1(gy + 1);
+                        if (ch + 2 < ci) gq[c].z = ld1(gy + 2);
+                        if (ch + 3 < ci) gq[c].w = ld1(gy + 3);
+                    }
+                }
+            }
+            int cnt = 0;
+            // flush the pool into the accumulators of every channel chunk (balanced over the S slots)
+            auto flush = [&](int total) {
+                wave_lds_sync();
+                total = min(total, POOL);
+                const int per = (total + S - 1) / S;
+                const int lo = slot * per;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (cg0 + c * CC >= ci) break;                      // wave-uniform
+                    const int chl = chok[c] ? cg0 + c * CC + 4 * j : 0;
+                    const int hi = chok[c] ? min(lo + per, total) : lo;
+                    for (int it = 0; it < per; it += 4) {
+                        float4 v[4];
+                        float w[4];
+                        uint2 e[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            e[u] = pool[min(lo + it + u, POOL + 7)];
+                            keep_unconditional(e[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool ok = lo + it + u < hi;
+                            e[u].x = ok ? e[u].x : 0u;
+                            w[u] = ok ? __uint_as_float(e[u].y) : 0.0f;
+                            v[u] = load_row_piece<VEC>(dwf, e[u].x, ci, chl);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc[c].x = fmaf(w[u], v[u].x, acc[c].x);
+                            acc[c].y = fmaf(w[u], v[u].y, acc[c].y);
+                            acc[c].z = fmaf(w[u], v[u].z, acc[c].z);
+                            acc[c].w = fmaf(w[u], v[u].w, acc[c].w);
+                        }
+                    }
+                }
+                wave_lds_sync();
+            };
+            // list + flush of the slab entries [base, base + 64) (entries >= cnt are dead lanes)
+            auto process = [&](int base) {
+                const int p = base + lane;
+                const bool real = p < cnt;
+                const float4 c = slab[real ? p : 0];
+                const int q = real ? __float_as_int(c.w) : 0;
+                const float nx = sx - c.x, ny = sy - c.y, nz = sz - c.z;
+                int total = 0, maxlen = 0;
+                if constexpr (MODE == 2) {
+                    const float4* kq = g.kp4 + (int64_t)q * K;
+                    kp_list_def<K>(nx, ny, nz, real, kq, inv_extent, (unsigned)(q * K), pool, segs, lane, total, maxlen);
+                    if (total <= POOL) {
+                        flush(total);
+                    } else {
+                        for (int sub = 0; sub < 4; ++sub) {
+                            total = 0; maxlen = 0;
+                            kp_list_def<K>(nx, ny, nz, real && (lane >> 4) == sub, kq, inv_extent, (unsigned)(q * K), pool, segs, lane,
+                                           total, maxlen);
+                            flush(total);
+                        }
+                    }
+                } else {
+                    const float* lkp = deformed_kp ? deformed_kp + (int64_t)q * (3 * K) : kernel_points;
+                    const float* lmod = modulations ? modulations + (int64_t)q * K : nullptr;
+                    auto kp = [&](int k, int cidx) { return MODE == 0 ? kpr[MODE == 0 ? 3 * k + cidx : 0] : lkp[3 * k + cidx]; };
+                    auto nomin = [&](int, float) {};
+                    kp_list<K, MODE == 2 ? 1 : MODE>(nx, ny, nz, real, kp, g, inv_extent, (unsigned)(q * K), 1u, lmod, pool, segs, lane,
+                                                     total, maxlen, nomin);
+                    if (total <= POOL) {
+                        flush(total);
+                    } else {
+                        for (int sub = 0; sub < 4; ++sub) {
+                            total = 0; maxlen = 0;
+                            kp_list<K, MODE == 2 ? 1 : MODE>(nx, ny, nz, real && (lane >> 4) == sub, kp, g, inv_extent, (unsigned)(q * K),
+                                                             1u, lmod, pool, segs, lane, total, maxlen, nomin);
+                            flush(total);
+                        }
+                    }
+                }
+            };
+            // candidates enter through here; when fewer than 64 free slots remain the full batches are consumed
+            auto take = [&](const float4& c, bool active) {
+                const float d2 = ref_d2(c.x, c.y, c.z, make_float4(sx, sy, sz, 0.0f));
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)s;
+                bool hit = active && d2 < r2;
+                hit = hit && key <= key_last[hit ? __float_as_int(c.w) : 0];
+                const unsigned long long m = __ballot(hit);
+                const int pos = cnt + lane_rank(m);
+                slab[hit ? pos : SLAB + lane] = c;                  // pos < SLAB: cnt <= SLAB - 64 on entry
+                cnt += __builtin_popcountll(m);
+                if (cnt > SLAB - 64) {
+                    wave_lds_sync();
+                    int base = 0;
+                    for (; base + 64 <= cnt; base += 64) process(base);
+                    const int rem = cnt - base;
+                    const float4 t = slab[base + (lane < rem ? lane : 0)];
+                    wave_lds_sync();
+                    if (lane < rem) slab[lane] = t;
+                    cnt = rem;
+                    wave_lds_sync();
+                }
+            };
+            if (from_row) {
+                for (int h0 = 0; h0 < g.rows_h; h0 += 64) {
+                    const int col = h0 + lane;
+                    const int64_t qi = col < g.rows_h ? g.rows[s * g.rows_h + col] : -1;
+                    const bool active = qi >= 0 && qi < ns;
+                    const int64_t qq = active ? qi : 0;
+                    take(make_float4(s_pts[3 * qq + 0], s_pts[3 * qq + 1], s_pts[3 * qq + 2], __int_as_float((int)qq)), active);
+                }
+            } else if (gr.s_len > 0) {
+                const int cx = cell_coord(sx, gr.lo[0], gr.inv_cell);
+                const int cy = cell_coord(sy, gr.lo[1], gr.inv_cell);
+                const int cz = cell_coord(sz, gr.lo[2], gr.inv_cell);
+                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gr.nx - 1);
+                if (lane < 9) {
+                    const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
+                    const bool ok = x0 <= x1 && z >= 0 && z < gr.nz && y >= 0 && y < gr.ny;
+                    const int row = gr.cell_base + ((ok ? z : 0) * gr.ny + (ok ? y : 0)) * gr.nx;
+                    runs[lane] = make_int2(ok ? cell_start[row + x0] : 0, ok ? cell_start[row + x1 + 1] : 0);
+                }
+                wave_lds_sync();
+                for (int r = 0; r < 9; ++r) {
+                    const int2 run = runs[r];
+                    const int rb = __builtin_amdgcn_readfirstlane(run.x), re = __builtin_amdgcn_readfirstlane(run.y);
+                    for (int p0 = rb; p0 < re; p0 += 64) {
+                        const int p = p0 + lane;
+                        take(sorted[p < re ? p : rb], p < re);
+                    }
+                }
+            }
+            wave_lds_sync();
+            for (int base = 0; base < cnt; base += 64) process(base);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (cg0 + c * CC >= ci) break;
+#pragma unroll
+                for (int o = G; o < 64; o <<= 1) {
+                    acc[c].x += __shfl_xor(acc[c].x, o, 64);
+                    acc[c].y += __shfl_xor(acc[c].y, o, 64);
+                    acc[c].z += __shfl_xor(acc[c].z, o, 64);
+                    acc[c].w += __shfl_xor(acc[c].w, o, 64);
+                }
+                if (slot == 0) {
+                    const int ch = cg0 + c * CC + 4 * j;
+                    T* dst = dx + s * ci + ch;
+                    float4 a = acc[c];
+                    if (g.gate) {
+                        a.x *= gq[c].x > 0.0f ? 1.0f : g.gate_slope; a.y *= gq[c].y > 0.0f ? 1.0f : g.gate_slope;
+                        a.z *= gq[c].z > 0.0f ? 1.0f : g.gate_slope; a.w *= gq[c].w > 0.0f ? 1.0f : g.gate_slope;
+                    }
+                    if (VEC) {
+                        if (chok[c]) st4(dst, a);
+                    } else {
+                        if (ch + 0 < ci) st1(dst + 0, a.x);
+                        if (ch + 1 < ci) st1(dst + 1, a.y);
+                        if (ch + 2 < ci) st1(dst + 2, a.z);
+                        if (ch + 3 < ci) st1(dst + 3, a.w);
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
 }  // namespace
 
 // 1 = entry pool + VALU accumulate (kpconv_gather_fwd_kernel), 2 = matrix core (kpconv_gather_fwd_mfma_kernel);
@@ -1618,9 +2108,204 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
     return WS_OK;
 }
 
+// ---- deformable fast path (MODE 2) and the wide-row grid backward: launchers -------------------------------------------
+template <typename T>
+int gather_fwd_def_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                        const T* x, int32_t ci, const float4* kp4, int32_t k, float extent, const int32_t* order, T* wf,
+                        float* min_d2, void* stream)
+{
+    int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM);
+    if (rc) return rc;
+    if (nq == 0) return WS_OK;
+    WS_REQUIRE(inds && x && wf && kp4, "NULL argument");
+    WS_REQUIRE(aligned16(kp4), "kp4 must be 16-byte aligned");
+    WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
+    GeomParams g{extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, 1, 0, nullptr, 0.0f, nullptr, 0, kp4};
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ws_grid(nq, 4);
+    int nt = ci <= 16 ? 1 : (ci <= 32 ? 2 : (ci <= 64 ? 4 : (ci <= 128 ? 8 : 16)));
+    if (!((ci % nt == 0) && (nt == 1 || (aligned16(x) && aligned16(wf))))) nt = 1;
+    if (sizeof(T) == 2 && nt == 1 && (ci % 2)) return ws_fail(WS_ERR_UNSUPPORTED, "bf16 rows need an even channel count (ci=%d)", ci);
+#define WS_FWDD(NTV) \
+    kpconv_gather_fwd_mfma_kernel<NTV, 2, true, true, T><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, nullptr, nullptr, \
+                                                                              nullptr, g, wf, min_d2, order)
+    if (nt == 1) WS_FWDD(1);
+    else if (nt == 2) WS_FWDD(2);
+    else if (nt == 4) WS_FWDD(4);
+    else if (nt == 8) WS_FWDD(8);
+    else WS_FWDD(16);
+#undef WS_FWDD
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+template <typename T>
+int gather_bwd_x_def_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, int32_t h,
+                          const int32_t* t_offsets, const int32_t* t_pairs, const T* dwf, int32_t ci, const float4* kp4,
+                          int32_t k, float extent, const int32_t* order, T* dx, void* stream)
+{
+    constexpr bool F32 = sizeof(T) == 4;
+    int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM);
+    if (rc) return rc;
+    if (ns == 0) return WS_OK;
+    WS_REQUIRE(t_offsets && t_pairs && dwf && dx && kp4 && aligned16(kp4), "NULL / unaligned argument");
+    WS_REQUIRE(nq * (int64_t)h < (1ll << 31), "nq*h exceeds int32");
+    WS_REQUIRE(nq * (int64_t)k * ci < (1ll << 31), "nq*k*ci exceeds the 32-bit row offsets of the gather");
+    GeomParams g{extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, 1, 0, nullptr, 0.0f, nullptr, 0, kp4};
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ws_grid(ns, 4);
+    const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
+    WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
+#define WS_BWDD2(G, VECV)                                                                                            \
+    do {                                                                                                             \
+        if constexpr (F32 || VECV)                                                                                   \
+            kpconv_gather_bwd_x_kernel<15, G, 2, VECV, T><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, dwf, ci, \
+                                                                               nullptr, nullptr, nullptr, g, dx, order); \
+    } while (0)
+#define WS_BWDD(G) do { if (vec4) WS_BWDD2(G, true); else WS_BWDD2(G, false); } while (0)
+    if (ci <= 4) WS_BWDD(1);
+    else if (ci <= 8) WS_BWDD(2);
+    else if (ci <= 16) WS_BWDD(4);
+    else if (ci <= 32) WS_BWDD(8);
+    else WS_BWDD(16);
+#undef WS_BWDD2
+#undef WS_BWDD
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+template <typename T>
+int gather_bwd_x_gridw_impl(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                            const uint64_t* key_last, float radius, const T* dwf, int32_t ci, const float* kernel_points,
+                            int32_t k, const float4* kp4, float extent, const int32_t* order, const int64_t* rows, int32_t rows_h,
+                            T* dx, void* stream)
+{
+    constexpr bool F32 = sizeof(T) == 4;
+    int rc = check_common(s_pts, ns, s_pts, ns, 1, ci, k, extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM);
+    if (rc) return rc;
+    if (ns == 0) return WS_OK;
+    WS_REQUIRE(grid_blob && key_last && dwf && dx && (kernel_points || kp4), "NULL argument");
+    WS_REQUIRE(!kp4 || aligned16(kp4), "kp4 must be 16-byte aligned");
+    WS_REQUIRE(nb >= 1 && cells >= 1, "bad grid nb=%d cells=%lld", nb, (long long)cells);
+    WS_REQUIRE(ns * (int64_t)k * ci < (1ll << 31), "ns*k*ci exceeds the 32-bit row offsets of the gather");
+    WS_REQUIRE(!rows || rows_h >= 1, "index rows given without their width");
+    GeomParams g{extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, kp4 ? 1 : 0, 0, nullptr, 0.0f,
+                 ws_kpconv_grid_rows ? rows : nullptr, rows_h, kp4};
+    hipStream_t st = (hipStream_t)stream;
+    const char* base = (const char*)grid_blob;
+    const CloudGrid* grids = (const CloudGrid*)base;
+    const int32_t* cell_start = (const int32_t*)(base + ws_grid_blob_cells_off(nb));
+    const float4* sorted = (const float4*)(base + ws_grid_blob_sorted_off(nb, cells));
+    const float r2 = radius * radius;
+    const unsigned long long* kl = reinterpret_cast<const unsigned long long*>(key_last);
+    const int grid = ws_grid(ns, 4);
+    const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
+    WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
+#define WS_GW2(G, MODEV, VECV)                                                                                        \
+    do {                                                                                                              \
+        if constexpr (F32 || VECV)                                                                                    \
+            kpconv_gather_bwd_x_gridw_kernel<15, G, MODEV, VECV, T><<<grid, 256, 0, st>>>(                             \
+                s_pts, ns, grids, nb, cell_start, sorted, kl, r2, dwf, ci, kernel_points, nullptr, nullptr, g, dx, order); \
+    } while (0)
+#define WS_GW(G)                                                                        \
+    do {                                                                                \
+        if (kp4) { if (vec4) WS_GW2(G, 2, true); else WS_GW2(G, 2, false); }             \
+        else { if (vec4) WS_GW2(G, 0, true); else WS_GW2(G, 0, false); }                 \
+    } while (0)
+    if (ci <= 4) WS_GW(1);
+    else if (ci <= 8) WS_GW(2);
+    else if (ci <= 16) WS_GW(4);
+    else if (ci <= 32) WS_GW(8);
+    else WS_GW(16);
+#undef WS_GW2
+#undef WS_GW
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+template <typename T>
+int gather_bwd_geom_def_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                             const T* x, int32_t ci, const T* dwf, const float4* kp4, int32_t k, const float* d_min_d2,
+                             float extent, const int32_t* order, float4* d_kp4, void* stream)
+{
+    int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM);
+    if (rc) return rc;
+    if (nq == 0) return WS_OK;
+    WS_REQUIRE(inds && x && dwf && kp4 && d_kp4 && aligned16(kp4) && aligned16(d_kp4), "NULL / unaligned argument");
+    WS_REQUIRE(ns * (int64_t)ci < (1ll << 31) && nq * (int64_t)k * ci < (1ll << 31), "row offsets exceed 32 bits");
+    if (ci % 16 != 0 || !aligned16(x) || !aligned16(dwf))
+        return ws_fail(WS_ERR_UNSUPPORTED, "geometry backward on the matrix core needs ci %% 16 == 0 and 16-byte aligned rows (ci=%d)", ci);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = ws_grid(nq, 4);
+#define WS_K6(CKV, AREGV) \
+    kpconv_gather_bwd_geom_def_kernel<CKV, AREGV, T><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf, kp4, d_min_d2, \
+                                                                           extent, d_kp4, order)
+    if (ci == 16) WS_K6(4, true);
+    else if (ci == 32) WS_K6(8, true);
+    else if (ci == 64) WS_K6(16, true);
+    else if (ci == 128) WS_K6(32, true);
+    else if (ci % 128 == 0) WS_K6(32, false);
+    else if (ci % 64 == 0) WS_K6(16, false);
+    else if (ci % 32 == 0) WS_K6(8, false);
+    else WS_K6(4, false);
+#undef WS_K6
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// ---- deformable fast path: deformable (+ modulated) KPConv with linear influence and sum aggregation, the per-query kernel
+//      points packed as kp4 [nq, 15] float4 (x, y, z, modulation; ws_kpconv_deform_prepare).  rows_bf16: feature rows
+//      (x, wf, dwf, dx) are bf16 instead of f32.
+int ws_kpconv_gather_fwd_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                             const void* x, int32_t ci, const float* kp4, int32_t k, float extent, const int32_t* order,
+                             void* wf, float* min_d2, int32_t rows_bf16, void* stream)
+{
+    const float4* kq = reinterpret_cast<const float4*>(kp4);
+    if (rows_bf16)
+        return gather_fwd_def_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, (const bf16_t*)x, ci, kq, k, extent, order, (bf16_t*)wf, min_d2, stream);
+    return gather_fwd_def_impl<float>(q_pts, nq, s_pts, ns, inds, h, (const float*)x, ci, kq, k, extent, order, (float*)wf, min_d2, stream);
+}
+
+int ws_kpconv_gather_bwd_x_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, int32_t h,
+                               const int32_t* t_offsets, const int32_t* t_pairs, const void* dwf, int32_t ci, const float* kp4,
+                               int32_t k, float extent, const int32_t* order, void* dx, int32_t rows_bf16, void* stream)
+{
+    const float4* kq = reinterpret_cast<const float4*>(kp4);
+    if (rows_bf16)
+        return gather_bwd_x_def_impl<bf16_t>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, (const bf16_t*)dwf, ci, kq, k, extent, order, (bf16_t*)dx, stream);
+    return gather_bwd_x_def_impl<float>(q_pts, nq, s_pts, ns, h, t_offsets, t_pairs, (const float*)dwf, ci, kq, k, extent, order, (float*)dx, stream);
+}
+
+// the table-free backward for any in-degree (rows wider than 128): rigid (kp4 NULL, kernel_points given) or deformable (kp4)
+int ws_kpconv_gather_bwd_x_grid_wide(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
+                                     const uint64_t* key_last, float radius, const void* dwf, int32_t ci,
+                                     const float* kernel_points, int32_t k, const float* kp4, float extent, const int32_t* order,
+                                     const int64_t* rows, int32_t rows_h, void* dx, int32_t rows_bf16, void* stream)
+{
+    const float4* kq = reinterpret_cast<const float4*>(kp4);
+    if (rows_bf16)
+        return gather_bwd_x_gridw_impl<bf16_t>(s_pts, ns, grid_blob, nb, cells, key_last, radius, (const bf16_t*)dwf, ci, kernel_points, k,
+                                               kq, extent, order, rows, rows_h, (bf16_t*)dx, stream);
+    return gather_bwd_x_gridw_impl<float>(s_pts, ns, grid_blob, nb, cells, key_last, radius, (const float*)dwf, ci, kernel_points, k, kq,
+                                          extent, order, rows, rows_h, (float*)dx, stream);
+}
+
+int ws_kpconv_gather_bwd_geom_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                                  const void* x, int32_t ci, const void* dwf, const float* kp4, int32_t k, const float* d_min_d2,
+                                  float extent, const int32_t* order, float* d_kp4, int32_t rows_bf16, void* stream)
+{
+    const float4* kq = reinterpret_cast<const float4*>(kp4);
+    float4* dk = reinterpret_cast<float4*>(d_kp4);
+    if (rows_bf16)
+        return gather_bwd_geom_def_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, (const bf16_t*)x, ci, (const bf16_t*)dwf, kq, k, d_min_d2,
+                                                extent, order, dk, stream);
+    return gather_bwd_geom_def_impl<float>(q_pts, nq, s_pts, ns, inds, h, (const float*)x, ci, (const float*)dwf, kq, k, d_min_d2, extent,
+                                           order, dk, stream);
+}
 
 int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
                          const int64_t* inds, int32_t h, const float* x, int32_t ci,

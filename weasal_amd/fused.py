@@ -221,7 +221,8 @@ def _geometry(conv, q_pts, s_pts, inds, strided):
     nq, ns = g.q_pts.shape[0], g.s_pts.shape[0]
     self_query = nq == ns and g.q_pts.data_ptr() == g.s_pts.data_ptr()
     grid = ops._grid_for(g.inds) if self_query else None
-    g.grid = grid if (grid is not None and grid.ns == ns) else None
+    # (the block calls know the slab form of the grid backward only: rows up to 128 neighbours)
+    g.grid = grid if (grid is not None and grid.ns == ns and grid.max_count <= ops.GRID_NARROW_MAX) else None
     g.table = None
     g.strided = strided
     return g

@@ -149,7 +149,7 @@ _grids = {}
 class SearchGrid:
     """What ws_kpconv_gather_bwd_x_grid needs of one self-query search: the exported cell grid, the key of the
     last kept neighbour per query, the radius; `overflow` is the kernel's (never expected) capacity flag."""
-    __slots__ = ("blob", "nb", "cells", "ns", "key_last", "radius", "overflow")
+    __slots__ = ("blob", "nb", "cells", "ns", "key_last", "radius", "overflow", "max_count", "cap")
 
     def tensors(self):
         return (self.blob, self.key_last, self.overflow)
@@ -160,6 +160,9 @@ def set_search_grids(pairs):
     _grids.clear()
     for inds, grid in pairs:
         _grids[(inds.data_ptr(), tuple(inds.shape))] = (inds, grid)
+
+
+GRID_NARROW_MAX = 128      # rows up to this length: the slab form of the grid backward (ws_kpconv_gather_bwd_x_grid); wider: _wide
 
 
 def _grid_for(inds):
@@ -225,7 +228,15 @@ class _KPConvGather(torch.autograd.Function):
             dx = torch.empty_like(x)
             grid = _grid_for(inds) if (nq == ns and q_pts.data_ptr() == s_pts.data_ptr()) else None
             tok = _tbegin("kpconv_gather_bwd_x", nq, h, ci)
-            if grid is not None and grid.ns == ns:
+            wide = grid is not None and grid.max_count > GRID_NARROW_MAX
+            if wide and not (dkp is None and mod is None and influence == 0 and aggregation == 0):
+                grid = None          # the queue form of the grid backward covers linear / sum only: transposed table
+            if grid is not None and grid.ns == ns and wide:
+                check(lib.ws_kpconv_gather_bwd_x_grid_wide(ptr(s_pts), ns, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last),
+                                                           grid.radius, ptr(dwf), ci, ptr(kernel_points), k, None, extent,
+                                                           ptr(_order_for(s_pts)), ptr(inds), h, ptr(dx), 1 if bf else 0,
+                                                           current_stream()))
+            elif grid is not None and grid.ns == ns:
                 # self-query layer: incoming pairs re-derived from the search grid, no transposed table
                 check(f_grid(ptr(s_pts), ns, ptr(grid.blob), grid.nb, grid.cells,
                                                       ptr(grid.key_last), grid.radius, ptr(dwf), ci, ptr(kernel_points), k,
@@ -260,6 +271,163 @@ def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linea
         inds = inds.to(torch.int64)
     return _KPConvGather.apply(x, deformed_kp, modulations, q_pts, s_pts, inds, kernel_points, extent,
                                INFLUENCE[influence], AGGREGATION[aggregation], want_min_d2)
+
+
+_KPCONV_GATHER_SELF = kpconv_gather      # (oracle.kpconv_ref.cpu_reference_mode swaps ops.kpconv_gather: then no fast paths)
+
+
+# ------------------------------------------------------------------------------------------------
+# deformable fast path (BASELINE config 5): linear influence, sum aggregation, packed kernel points
+# ------------------------------------------------------------------------------------------------
+class _DeformPrepare(torch.autograd.Function):
+    """offset features [N, 3K | 4K] -> (kp4 [N,K,4], deformed_kp [N,K,3], modulations [N,K] | None)
+    (models/blocks.py:250-267, 287-288; ws_kpconv_deform_prepare)"""
+
+    @staticmethod
+    def forward(ctx, off, kernel_points, extent, modulated):
+        lib = _lib.lib()
+        _need_cuda(off, kernel_points)
+        off = off.float().contiguous()
+        n, od = off.shape
+        k = kernel_points.shape[0]
+        kp4 = torch.empty((n, k, 4), dtype=torch.float32, device=off.device)
+        dkp = torch.empty((n, k, 3), dtype=torch.float32, device=off.device)
+        mod = torch.empty((n, k), dtype=torch.float32, device=off.device) if modulated else None
+        check(lib.ws_kpconv_deform_prepare(ptr(off), n, od, ptr(kernel_points), k, float(extent), 1 if modulated else 0,
+                                           ptr(dkp), ptr(mod), ptr(kp4), current_stream()))
+        ctx.save_for_backward(kp4)
+        ctx.cfg = (n, od, k, float(extent), bool(modulated))
+        ctx.mark_non_differentiable(*([mod] if mod is not None else []))
+        return kp4, dkp, mod
+
+    @staticmethod
+    def backward(ctx, d_kp4, d_dkp, d_mod):
+        lib = _lib.lib()
+        kp4, = ctx.saved_tensors
+        n, od, k, extent, modulated = ctx.cfg
+        d_off = torch.empty((n, od), dtype=torch.float32, device=kp4.device)
+        if d_kp4 is None and d_dkp is None:
+            return d_off.zero_(), None, None, None
+        d_kp4 = d_kp4.float().contiguous() if d_kp4 is not None else None
+        d_dkp = d_dkp.float().contiguous() if d_dkp is not None else None
+        check(lib.ws_kpconv_deform_prepare_bwd(ptr(d_kp4), ptr(d_dkp), ptr(kp4), n, od, k, extent, 1 if modulated else 0,
+                                               ptr(d_off), current_stream()))
+        return d_off, None, None, None
+
+
+def deform_prepare(offset_features, kernel_points, extent, modulated):
+    """-> (kp4, deformed_kp, modulations or None); `modulations` is a plain copy for the module attribute (its gradient
+    travels through kp4)"""
+    return _DeformPrepare.apply(offset_features, _f32c(kernel_points), float(extent), bool(modulated))
+
+
+def deform_fast_path_ok(x, k, influence, aggregation):
+    """the packed-kernel-point kernels cover: K = 15, linear influence, sum aggregation, GPU rows of a multiple of 16 channels"""
+    return (x.is_cuda and k == 15 and influence == "linear" and aggregation == "sum" and x.dim() == 2 and x.shape[1] % 16 == 0
+            and x.dtype in (torch.float32, torch.bfloat16) and kpconv_gather is _KPCONV_GATHER_SELF)
+
+
+class _KPConvGatherDef(torch.autograd.Function):
+    """wf[q,k,c] = mod[q,k] sum_h w(q,h,k) x[inds[q,h],c] with per-query kernel points (kp4), and min_d2 [nq,K]
+    (models/blocks.py:278-367 for deformable = True, KP_influence = 'linear', aggregation_mode = 'sum')"""
+
+    @staticmethod
+    def forward(ctx, x, kp4, q_pts, s_pts, inds, extent):
+        lib = _lib.lib()
+        _need_cuda(x, kp4, q_pts, s_pts, inds)
+        x = x.contiguous()
+        kp4 = kp4.contiguous()
+        nq, h = inds.shape
+        ns, ci = x.shape
+        k = kp4.shape[1]
+        bf = x.dtype == torch.bfloat16
+        wf = torch.empty((nq, k, ci), dtype=x.dtype, device=x.device)
+        min_d2 = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+        tok = _tbegin("kpconv_gather_fwd", nq, h, ci)
+        check(lib.ws_kpconv_gather_fwd_def(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(kp4), k, float(extent),
+                                           ptr(_order_for(q_pts)), ptr(wf), ptr(min_d2), 1 if bf else 0, current_stream()))
+        _tend(tok)
+        ctx.save_for_backward(x, kp4, q_pts, s_pts, inds)
+        ctx.extent = float(extent)
+        return wf, min_d2
+
+    @staticmethod
+    def backward(ctx, dwf, d_min_d2):
+        lib = _lib.lib()
+        x, kp4, q_pts, s_pts, inds = ctx.saved_tensors
+        extent = ctx.extent
+        nq, h = inds.shape
+        ns, ci = x.shape
+        k = kp4.shape[1]
+        bf = 1 if x.dtype == torch.bfloat16 else 0
+        dwf = dwf.contiguous() if dwf.dtype == x.dtype else dwf.to(x.dtype).contiguous()
+        dx = d_kp4 = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            grid = _grid_for(inds) if (nq == ns and q_pts.data_ptr() == s_pts.data_ptr()) else None
+            tok = _tbegin("kpconv_gather_bwd_x", nq, h, ci)
+            if grid is not None and grid.ns == ns:
+                check(lib.ws_kpconv_gather_bwd_x_grid_wide(ptr(s_pts), ns, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last),
+                                                           grid.radius, ptr(dwf), ci, None, k, ptr(kp4), extent,
+                                                           ptr(_order_for(s_pts)), ptr(inds), h, ptr(dx), bf, current_stream()))
+            else:
+                table = transposed_table(inds, ns)
+                check(lib.ws_kpconv_gather_bwd_x_def(ptr(q_pts), nq, ptr(s_pts), ns, h, ptr(table.offsets), ptr(table.pairs),
+                                                     ptr(dwf), ci, ptr(kp4), k, extent, ptr(_order_for(s_pts)), ptr(dx), bf,
+                                                     current_stream()))
+            _tend(tok)
+        if ctx.needs_input_grad[1]:
+            d_kp4 = torch.empty_like(kp4)
+            dmin = d_min_d2.float().contiguous() if d_min_d2 is not None else None
+            tok = _tbegin("kpconv_gather_bwd_geom", nq, h, ci)
+            check(lib.ws_kpconv_gather_bwd_geom_def(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(dwf), ptr(kp4), k,
+                                                    ptr(dmin), extent, ptr(_order_for(q_pts)), ptr(d_kp4), bf, current_stream()))
+            _tend(tok)
+        return dx, d_kp4, None, None, None, None
+
+
+def kpconv_gather_def(x, kp4, q_pts, s_pts, inds, extent):
+    """deformable fast path: -> (wf [nq,K,ci], min_d2 [nq,K])"""
+    inds = inds.contiguous()
+    if inds.dtype != torch.int64:
+        inds = inds.to(torch.int64)
+    return _KPConvGatherDef.apply(x, kp4, _f32c(q_pts), _f32c(s_pts), inds, float(extent))
+
+
+class _P2PRegularizer(torch.autograd.Function):
+    """(fitting, repulsive) of one deformable layer (models/architectures.py:36-51): ws_p2p_regularizer_fwd / _bwd"""
+
+    @staticmethod
+    def forward(ctx, deformed_kp, min_d2, extent, repulse_extent):
+        lib = _lib.lib()
+        _need_cuda(deformed_kp, min_d2)
+        dkp = deformed_kp.float().contiguous()
+        md = min_d2.float().contiguous()
+        n, k = md.shape
+        out = torch.empty(2, dtype=torch.float32, device=md.device)
+        scratch = torch.empty(max(lib.ws_p2p_regularizer_scratch_bytes(n), 16), dtype=torch.uint8, device=md.device)
+        check(lib.ws_p2p_regularizer_fwd(ptr(dkp), None, ptr(md), n, k, float(extent), float(repulse_extent), ptr(out), ptr(scratch),
+                                         current_stream()))
+        ctx.save_for_backward(dkp, md)
+        ctx.cfg = (float(extent), float(repulse_extent))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.lib()
+        dkp, md = ctx.saved_tensors
+        n, k = md.shape
+        extent, rep = ctx.cfg
+        g = g.float().contiguous()
+        d_md = torch.empty_like(md)
+        d_dkp = torch.empty_like(dkp)
+        check(lib.ws_p2p_regularizer_bwd(ptr(dkp), None, ptr(md), n, k, extent, rep, ptr(g), ptr(d_md), ptr(d_dkp), current_stream()))
+        return d_dkp, d_md, None, None
+
+
+def p2p_regularizer(deformed_kp, min_d2, extent, repulse_extent):
+    """-> tensor [2] = (fitting loss, repulsive loss) of one deformable KPConv layer"""
+    return _P2PRegularizer.apply(deformed_kp, min_d2, float(extent), float(repulse_extent))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -772,6 +940,8 @@ class DeferredSearches:
                 check(lib.ws_radius_neighbors_reuse_grid(ws, 1))
             if want_grid:
                 grid = SearchGrid()
+                grid.max_count = 0            # true maximum row length of the search: set by the caller after finish()
+                grid.cap = 1024 if width > 128 else 128      # sort slab of the asynchronous pass: key_last is valid up to it
                 grid.key_last = torch.empty((q.shape[0],), dtype=torch.int64, device=q.device)
                 grid.radius = float(np.float32(radius))
                 grid.overflow = torch.zeros((1,), dtype=torch.int32, device=q.device)

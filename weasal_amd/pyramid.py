@@ -132,9 +132,11 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
         for (lst, pos), mat in zip(slots, final):
             lst[pos] = mat
         for slot, grid in pending_grids:
-            # usable while no row of that search exceeded the 128-entry fast path (then the in-degree of a
-            # support is bounded by it as well); otherwise the layer keeps the transposed-table backward
-            if 0 < deferred.last_counts[slot] <= 128:
+            # the true maximum row length decides which grid backward the layer takes: the slab form up to 128 (the
+            # in-degree of a support is bounded by the longest row), the queue form beyond (any in-degree); a search
+            # that had to be redone synchronously (rows beyond the sort slab) built another grid: transposed table
+            grid.max_count = deferred.last_counts[slot]
+            if 0 < grid.max_count <= grid.cap:
                 search_grids.append((final[slot], grid))
     # the per-layer lengths go to the device in ONE copy (views of it are handed out)
     sizes = [len(a) for a in input_lengths]
