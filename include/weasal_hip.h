@@ -539,6 +539,13 @@ int ws_sgd_step(float* const* h_params, const float* const* h_grads, float* cons
  *   modulated) -> deformed_kp [n,k,3] = offset * extent + kernel_points (two roundings, like the reference's mul and
  *   add), modulations [n,k] = 2 sigmoid(last k columns) (NULL / ignored when not modulated), and kp4 [n,k] float4 =
  *   (x, y, z, modulation or 1): the packed operand of the entries below (16-byte aligned).  deformed_kp may be NULL.
+ *   kp_rmax (device float, may be NULL) receives max |deformed kernel point| of the call: ws_kpconv_gather_bwd_x_grid_wide
+ *   drops the pairs farther apart than kp_rmax + extent (no kernel point reaches them).
+ * rows_sorted != 0 (ws_kpconv_gather_fwd_def, _bwd_geom_def, ws_kpconv_gather_fwd_ex): the caller vouches that every index
+ *   row is sorted by distance from its query (what the radius search delivers).  A neighbour beyond the reach of every
+ *   kernel point (max |kp| + extent) has 15 zero influences and one beyond max_k (sqrt(min_d2[k]) + |kp_k|) cannot lower
+ *   a minimum: the walk over the row stops there.  Exact (the skipped terms are zeros); with the deformable search radius
+ *   (2 r against a reach of ~1.1 r) it skips most of every row.
  * ws_kpconv_deform_prepare_bwd: d offset_features [n, od] from d_kp4 [n,k,4] (NULL = zero) and / or a second gradient
  *   d_deformed_kp [n,k,3] of the positions (NULL = none; the regulariser's).
  * ws_kpconv_gather_fwd_def / _bwd_x_def / _bwd_geom_def: ws_kpconv_gather_fwd / _bwd_x / _bwd_geom for that mode with
@@ -557,22 +564,29 @@ int ws_sgd_step(float* const* h_params, const float* const* h_grads, float* cons
  *   scratch: ws_p2p_regularizer_scratch_bytes(n).
  * ------------------------------------------------------------------------------------------ */
 int ws_kpconv_deform_prepare(const float* offset_features, int64_t n, int32_t od, const float* kernel_points, int32_t k,
-                             float extent, int32_t modulated, float* deformed_kp, float* modulations, float* kp4, void* stream);
+                             float extent, int32_t modulated, float* deformed_kp, float* modulations, float* kp4, float* kp_rmax,
+                             void* stream);
 int ws_kpconv_deform_prepare_bwd(const float* d_kp4, const float* d_deformed_kp, const float* kp4, int64_t n, int32_t od, int32_t k,
                                  float extent, int32_t modulated, float* d_offset_features, void* stream);
 int ws_kpconv_gather_fwd_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
                              const void* x, int32_t ci, const float* kp4, int32_t k, float extent, const int32_t* order,
-                             void* wf, float* min_d2, int32_t rows_bf16, void* stream);
+                             void* wf, float* min_d2, int32_t rows_bf16, int32_t rows_sorted, void* stream);
+int ws_kpconv_gather_fwd_ex(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                            const void* x, int32_t ci, const float* kernel_points, int32_t k, const float* deformed_kp,
+                            const float* modulations, float extent, int32_t influence, int32_t aggregation, const int32_t* order,
+                            void* wf, float* min_d2, int32_t rows_bf16, int32_t rows_sorted, void* stream);
 int ws_kpconv_gather_bwd_x_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, int32_t h,
                                const int32_t* t_offsets, const int32_t* t_pairs, const void* dwf, int32_t ci, const float* kp4,
                                int32_t k, float extent, const int32_t* order, void* dx, int32_t rows_bf16, void* stream);
 int ws_kpconv_gather_bwd_x_grid_wide(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
                                      const uint64_t* key_last, float radius, const void* dwf, int32_t ci,
-                                     const float* kernel_points, int32_t k, const float* kp4, float extent, const int32_t* order,
-                                     const int64_t* rows, int32_t rows_h, void* dx, int32_t rows_bf16, void* stream);
+                                     const float* kernel_points, int32_t k, const float* kp4, const float* kp_rmax, float extent,
+                                     const int32_t* order, const int64_t* rows, int32_t rows_h, void* dx, int32_t rows_bf16,
+                                     void* stream);
 int ws_kpconv_gather_bwd_geom_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
                                   const void* x, int32_t ci, const void* dwf, const float* kp4, int32_t k, const float* d_min_d2,
-                                  float extent, const int32_t* order, float* d_kp4, int32_t rows_bf16, void* stream);
+                                  float extent, const int32_t* order, float* d_kp4, int32_t rows_bf16, int32_t rows_sorted,
+                                  void* stream);
 int64_t ws_p2p_regularizer_scratch_bytes(int64_t n);
 int ws_p2p_regularizer_fwd(const float* deformed_kp, const float* kp4, const float* min_d2, int64_t n, int32_t k, float extent,
                            float repulse_extent, float* out2, void* scratch, void* stream);

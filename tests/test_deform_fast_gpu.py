@@ -126,3 +126,62 @@ def test_grid_backward_queue_form_equals_transposed_table(gpu, ci):
     finally:
         ops.GRID_BACKWARD = True
     assert rel(dx_grid, dx_tab) < 2e-6
+
+
+@pytest.mark.parametrize("rows", ["f32", "bf16"])
+def test_sorted_row_cutoff_changes_nothing(gpu, rows):
+    """Rows that come from the radius search are sorted by distance; with the deformable search radius (2 r) most of a row
+    lies beyond the reach of every kernel point (0.69 r + extent) and the kernels stop there.  The skipped influences are
+    exact zeros and the skipped columns cannot hold a minimum: forward, min_d2 and every gradient must be BIT-identical to
+    the full walk (ops.SORTED_ROW_CUTOFF = False), rigid and deformable, self-query (grid backward) and strided (table)."""
+    from weasal_amd import config as wcfg, ops, pyramid
+    from weasal_amd.blocks import KPConv
+    cfg = wcfg.DALESDeformF32Config()
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-4, 4, size=(6000, 3)).astype(np.float32)
+    P = torch.from_numpy(pts).to(gpu)
+    np.random.seed(0)
+    batch = pyramid.build_batch(cfg, P, torch.ones(6000, 3, device=gpu), torch.zeros(6000, dtype=torch.int64, device=gpu),
+                                np.array([6000], np.int32), [300, 519, 472, 193, 34])
+    batch.activate()
+    dt = torch.bfloat16 if rows == "bf16" else torch.float32
+    for q, s, inds in ((batch.points[0], batch.points[0], batch.neighbors[0]), (batch.points[1], batch.points[0], batch.pools[0])):
+        assert ops.rows_are_sorted(inds) and inds.shape[1] >= 250
+        for deformable in (False, True):
+            np.random.seed(1)
+            torch.manual_seed(1)
+            conv = KPConv(15, 3, 32, 32, 0.4, 1.0, deformable=deformable, modulated=deformable).to(gpu)
+            if deformable:
+                with torch.no_grad():
+                    conv.offset_conv.weights.mul_(4.0)
+                    conv.offset_bias.normal_(0.0, 0.05)
+            x = torch.randn(s.shape[0], 32, device=gpu).to(dt)
+            dy = torch.randn(q.shape[0], 32, device=gpu).to(dt)
+            res = {}
+            for cut in (True, False):
+                ops.SORTED_ROW_CUTOFF = cut
+                try:
+                    conv.zero_grad()
+                    xg = x.clone().requires_grad_(True)
+                    out = conv(q, s, inds, xg)
+                    loss = (out.float() * dy.float()).sum()
+                    if deformable:
+                        loss = loss + 0.01 * conv.min_d2.sum() + 0.01 * (conv.deformed_KP ** 2).sum()
+                    loss.backward()
+                    res[cut] = {"out": out.detach(), "dW": conv.weights.grad.clone(), "dx": xg.grad.clone()}
+                    if deformable:
+                        res[cut].update(min_d2=conv.min_d2.detach(), dWo=conv.offset_conv.weights.grad.clone(),
+                                        dbo=conv.offset_bias.grad.clone())
+                finally:
+                    ops.SORTED_ROW_CUTOFF = True
+            a, b = res[True], res[False]
+            # the forward, min_d2 and what depends on them alone: the same sums over the same non-zero terms in the same order
+            for key in ("out", "dW", "min_d2"):
+                if key in a:
+                    assert torch.equal(a[key], b[key]), (key, deformable, tuple(inds.shape))
+            # dx of a grid-walk support groups its (fewer) surviving candidates into other batches of 64: fp32 re-association,
+            # nothing else; the gradients behind it inherit that
+            tol = 2e-6 if rows == "f32" else 1e-2
+            for key in ("dx", "dWo", "dbo"):
+                if key in a:
+                    assert rel(a[key], b[key]) < tol, (key, rel(a[key], b[key]), deformable, tuple(inds.shape))

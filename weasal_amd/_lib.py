@@ -112,14 +112,16 @@ SIGNATURES = {
     "ws_softmax_ce_fwd": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ws_softmax_ce_bwd": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "ws_sgd_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
-    "ws_kpconv_deform_prepare": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "ws_kpconv_deform_prepare": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ws_kpconv_gather_fwd_ex": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32, _i32, _i32, _vp,
+                                         _vp, _vp, _i32, _i32, _vp]),
     "ws_kpconv_deform_prepare_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _vp, _vp]),
-    "ws_kpconv_gather_fwd_def": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _i32, _vp]),
+    "ws_kpconv_gather_fwd_def": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ws_kpconv_gather_bwd_x_def": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _i32, _vp]),
-    "ws_kpconv_gather_bwd_x_grid_wide": (C.c_int, [_vp, _i64, _vp, _i32, _i64, _vp, _f32, _vp, _i32, _vp, _i32, _vp, _f32, _vp,
+    "ws_kpconv_gather_bwd_x_grid_wide": (C.c_int, [_vp, _i64, _vp, _i32, _i64, _vp, _f32, _vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp,
                                                    _vp, _i32, _vp, _i32, _vp]),
     "ws_kpconv_gather_bwd_geom_def": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
-                                                _i32, _vp]),
+                                                _i32, _i32, _vp]),
     "ws_p2p_regularizer_scratch_bytes": (_i64, [_i64]),
     "ws_p2p_regularizer_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp]),
     "ws_p2p_regularizer_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),

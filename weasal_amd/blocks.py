@@ -114,7 +114,7 @@ class KPConv(nn.Module):
         k_points = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
         return Parameter(torch.tensor(k_points, dtype=torch.float32), requires_grad=False)
 
-    def forward(self, q_pts, s_pts, neighb_inds, x, _bias=None, _slope=None, _out_f32=False):
+    def forward(self, q_pts, s_pts, neighb_inds, x, _bias=None, _slope=None, _out_f32=False, _rows_sorted=None):
         """`_bias` / `_slope` (used by the blocks of this module only): the BatchNormBlock bias and the
         LeakyReLU that follow the convolution, applied in the epilogue of the contraction GEMM.
         bf16 feature rows (x.dtype bfloat16, BASELINE config 5) run the bf16-row kernels; `_out_f32` keeps the
@@ -124,15 +124,21 @@ class KPConv(nn.Module):
         if self.aggregation_mode not in ops.AGGREGATION:
             raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
 
+        # index rows known to be sorted by distance (a matrix of the batch's pyramid): the linear-influence kernels stop at
+        # the reach of the kernel points
+        rows_sorted = (x.is_cuda and ops.rows_are_sorted(neighb_inds)) if _rows_sorted is None else _rows_sorted
         deformed = None
         modulations = None
         if self.deformable and DEFORM_FAST_PATH and ops.deform_fast_path_ok(x, self.K, self.KP_influence, self.aggregation_mode):
             # BASELINE config 5's mode (linear influence, sum): offsets, modulations and kernel points in one pass
             # (ws_kpconv_deform_prepare), per-query kernel points packed for the gather kernels; the offset bias rides on
             # the epilogue of the offset convolution's contraction
-            self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x, _bias=self.offset_bias, _out_f32=True)
-            kp4, self.deformed_KP, _ = ops.deform_prepare(self.offset_features, self.kernel_points, self.KP_extent, self.modulated)
-            wf, self.min_d2 = ops.kpconv_gather_def(x, kp4, q_pts, s_pts, neighb_inds, self.KP_extent)
+            self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x, _bias=self.offset_bias, _out_f32=True,
+                                                    _rows_sorted=rows_sorted)
+            kp4, self.deformed_KP, _, rmax = ops.deform_prepare(self.offset_features, self.kernel_points, self.KP_extent,
+                                                                self.modulated)
+            wf, self.min_d2 = ops.kpconv_gather_def(x, kp4, q_pts, s_pts, neighb_inds, self.KP_extent, kp_rmax=rmax,
+                                                    rows_sorted=rows_sorted)
             return ops.matmul_epilogue(wf.reshape(wf.shape[0], -1),
                                        self.weights.reshape(self.K * self.in_channels, self.out_channels),
                                        bias=_bias, slope=_slope, out_f32=_out_f32)
@@ -148,10 +154,11 @@ class KPConv(nn.Module):
             self.deformed_KP = unscaled * self.KP_extent + self.kernel_points      # blocks.py:267,288
             deformed = self.deformed_KP
 
+        kw = {"rows_sorted": True} if (rows_sorted and not self.deformable) else {}      # (the oracle's stand-in has no such argument)
         wf, min_d2 = ops.kpconv_gather(x, q_pts, s_pts, neighb_inds, self.kernel_points, self.KP_extent,
                                        influence=self.KP_influence, aggregation=self.aggregation_mode,
                                        deformed_kp=deformed, modulations=modulations,
-                                       want_min_d2=self.deformable)
+                                       want_min_d2=self.deformable, **kw)
         if self.deformable:
             self.min_d2 = min_d2                                                     # blocks.py:304
         # dense contraction over (kernel point, input channel): blocks.py:370-374

@@ -16,11 +16,12 @@ constexpr int KP = 15;
 __global__ __launch_bounds__(256) void deform_prepare_kernel(const float* __restrict__ off, int64_t n, int32_t od,
                                                              const float* __restrict__ kernel_points, float extent, int modulated,
                                                              float* __restrict__ deformed_kp, float* __restrict__ modulations,
-                                                             float4* __restrict__ kp4)
+                                                             float4* __restrict__ kp4, int* __restrict__ rmax_bits)
 {
 #pragma clang fp contract(off)
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (point, kernel point)
-    if (e >= n * KP) return;
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;            // (point, kernel point)
+    const bool tail = e >= n * KP;                                  // (tail lanes redo the last element: the wave reduction
+    if (tail) e = n * KP - 1;                                       //  below needs every lane; identical values are rewritten)
     const int64_t p = e / KP;
     const int k = (int)(e - p * KP);
     const float* row = off + p * od;
@@ -37,6 +38,13 @@ __global__ __launch_bounds__(256) void deform_prepare_kernel(const float* __rest
     if (deformed_kp) { deformed_kp[3 * e] = v[0]; deformed_kp[3 * e + 1] = v[1]; deformed_kp[3 * e + 2] = v[2]; }
     if (modulations && modulated) modulations[e] = m;
     kp4[e] = make_float4(v[0], v[1], v[2], m);
+    if (rmax_bits) {
+        // largest |kp| of the launch (non-negative floats order like their bit patterns): one atomic per wave
+        float r = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(rmax_bits, __float_as_int(r));
+    }
 }
 
 // d offset_features from d kp4 (the gather kernels' geometry gradient: xyz and modulation) and, optionally, a second
@@ -179,14 +187,17 @@ __global__ __launch_bounds__(256) void p2p_reg_bwd_kernel(const float* __restric
 extern "C" {
 
 int ws_kpconv_deform_prepare(const float* offset_features, int64_t n, int32_t od, const float* kernel_points, int32_t k,
-                             float extent, int32_t modulated, float* deformed_kp, float* modulations, float* kp4, void* stream)
+                             float extent, int32_t modulated, float* deformed_kp, float* modulations, float* kp4, float* kp_rmax,
+                             void* stream)
 {
     if (k != KP) return ws_fail(WS_ERR_UNSUPPORTED, "num_kernel_points=%d: this build instantiates K=15 only", k);
     WS_REQUIRE(n >= 0 && od == (modulated ? 4 : 3) * KP, "offset features must have %d columns (got %d)", (modulated ? 4 : 3) * KP, od);
     if (n == 0) return WS_OK;
     WS_REQUIRE(offset_features && kernel_points && kp4 && ((uintptr_t)kp4 & 15u) == 0, "NULL / unaligned argument");
+    if (kp_rmax) WS_HIP(hipMemsetAsync(kp_rmax, 0, sizeof(float), (hipStream_t)stream));
     deform_prepare_kernel<<<(unsigned)ws_ceil_div(n * KP, 256), 256, 0, (hipStream_t)stream>>>(
-        offset_features, n, od, kernel_points, extent, modulated, deformed_kp, modulations, reinterpret_cast<float4*>(kp4));
+        offset_features, n, od, kernel_points, extent, modulated, deformed_kp, modulations, reinterpret_cast<float4*>(kp4),
+        reinterpret_cast<int*>(kp_rmax));
     WS_LAUNCH_CHECK();
     return WS_OK;
 }

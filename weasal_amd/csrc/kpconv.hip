@@ -34,6 +34,9 @@ struct GeomParams {
     const float4* kp4;    // MODE 2 only (deformable / modulated, linear influence, sum): the per-query kernel points packed as
                           // [nq, 15] float4 = (x, y, z, modulation) -- ONE aligned 16-byte load per (query, kernel point)
                           // where the reference-shaped operands deformed_kp [nq,15,3] + modulations [nq,15] need four.
+    const float* rmax;    // K4G, MODE 2: device float = max over the queries of (max_k |kp_k|), written by
+                          // ws_kpconv_deform_prepare: a pair farther apart than that + extent has no influence (NULL: no bound)
+    int cut;              // pool-form K3 (MODE 0): 1 = rows are sorted by distance, stop at the influence reach (see CUT)
 };
 
 // Influence of the K kernel points on one neighbour offset n = s - q.  kp is wave-uniform.
@@ -327,9 +330,17 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
 
     // MODE 0: the rigid kernel points are wave-uniform for the whole launch -> registers (SGPRs)
     float kpr[MODE == 0 ? 3 * K : 1];
+    float cut2_pool = 3.4e38f;
     if (MODE == 0) {
 #pragma unroll
         for (int t = 0; t < 3 * K; ++t) kpr[t] = kernel_points[t];
+        if (g.cut) {
+            float rr = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) rr = fmaxf(rr, (kpr[3 * k] * kpr[3 * k] + kpr[3 * k + 1] * kpr[3 * k + 1]) + kpr[3 * k + 2] * kpr[3 * k + 2]);
+            const float R = (__builtin_sqrtf(rr) + g.extent) * 1.0001f;
+            cut2_pool = R * R;
+        }
     }
 
     // flush the pool: every slot walks the segments of its kernel points for all channel chunks.
@@ -468,6 +479,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_kernel(
             }
             const bool real = incol && idx >= 0;
             const float nx = px - qx, ny = py - qy, nz = pz - qz;
+            if (MODE == 0 && g.cut && h0 > 0) {
+                // sorted rows: once a chunk holds no neighbour inside the influence reach, neither does any later one
+                if (__ballot(real && (nx * nx + ny * ny) + nz * nz <= cut2_pool) == 0ull) break;
+            }
             const unsigned row = (unsigned)(real ? idx : 0);
             int total = 0, maxlen = 0;
             if (MODE == 0 && h - h0 > 64) {
@@ -598,7 +613,13 @@ template <int NT> struct RowLoad<NT, bf16_t> {
 };
 
 // VECROW: ci is a multiple of NT and rows are aligned for NT-element accesses (else NT == 1 with per-lane masking)
-template <int NT, int MODE, bool DEF, bool VECROW, typename T, int GSV = 0>
+// CUT (MODE 0 / 2 only): the caller vouches that every index row is sorted by distance from its query (what the radius search
+// delivers, neighbors.cpp:293).  A neighbour farther from the query than  max_k |kp_k| + extent  has 15 zero influences, and
+// one farther than  max_k (sqrt(min_d2[k] so far) + |kp_k|)  cannot lower any minimum (triangle inequality): the walk over
+// the row stops there.  Exact -- the skipped terms are zeros -- and decisive where the rows come from the DEFORMABLE radius
+// (datasets/common.py:500-502: 2 r, while the kernel points reach 0.69 r + extent = 1.09 r: 84 % of a rigid offset
+// convolution's neighbours, ~60 % of a deformed one's, are outside every influence).
+template <int NT, int MODE, bool DEF, bool VECROW, typename T, int GSV = 0, bool CUT = false>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci,
@@ -614,6 +635,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     constexpr int GS = GSV > 0 ? GSV : (NT <= 2 ? WS_K3_GS : (NT == 4 ? 2 : 1));
     static_assert(!(DEF && MODE == 0), "deformable layers use MODE 1 or 2");
     static_assert(MODE != 2 || DEF, "MODE 2 is the deformable fast path");
+    static_assert(!CUT || MODE == 0 || MODE == 2, "the distance cutoff belongs to the linear-influence fast paths");
     static_assert(VECROW || NT == 1, "masked rows use one channel per lane");
     __shared__ float4 nb_all[4][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -631,6 +653,18 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     if (!DEF && haskp) { kx = kernel_points[3 * i]; ky = kernel_points[3 * i + 1]; kz = kernel_points[3 * i + 2]; }
     if ((MODE == 0 || MODE == 2) && !haskp) kx = ky = kz = 1.0e9f;   // the 16th "kernel point": far from everything, weight 0
     float kmod = 0.0f;                                            // MODE 2: modulation of this lane's kernel point
+    // squared cutoff on the neighbour's distance from the query (CUT); rigid: a constant of the launch
+    auto group_max = [&](float v) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        return v;
+    };
+    float cut2_rigid = 3.4e38f;
+    if constexpr (CUT && MODE == 0) {
+        const float rr = group_max(haskp ? __builtin_sqrtf((kx * kx + ky * ky) + kz * kz) : 0.0f);
+        const float R = (rr + g.extent) * 1.0001f;
+        cut2_rigid = R * R;
+    }
 
     // ---- software pipeline over the items of this wave.  Everything an item needs before its row loads -- its query index
     // (order[]), its index row, the neighbours' coordinates, its own coordinates -- is a chain of dependent memory
@@ -698,6 +732,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
             kx = kp[0]; ky = kp[1]; kz = kp[2];
         }
         float mind = 3.4e38f;
+        float cut2 = cut2_rigid, rk = 0.0f, rq = 0.0f;
+        if constexpr (CUT && MODE == 2) {
+            rk = haskp ? __builtin_sqrtf((kx * kx + ky * ky) + kz * kz) : 0.0f;
+            rq = group_max(rk) + g.extent;                            // beyond it: no influence
+            cut2 = 3.4e38f;                                           // the first chunk is walked in full (min_d2 needs a start)
+        }
         for (int cb = 0; cb < ci; cb += CB) {
             f32x4v acc[NT];
 #pragma unroll
@@ -731,6 +771,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                     // pair (a, b) of a row group side by side, one ds_read_b128 each.
                     typedef float f2 __attribute__((ext_vector_type(2)));
                     float* nbf = reinterpret_cast<float*>(nb);       // [pair p = 0..7][kk = 0..3][8 floats]
+                    float dn2 = 0.0f;
                     {
                         const bool real = idx >= 0 && (h0 + lane < h);
                         float sx = real ? px - qx : WS_SHADOW, sy = real ? py - qy : WS_SHADOW, sz = real ? pz - qz : WS_SHADOW;
@@ -742,9 +783,16 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                         const int sstep = lane >> 2, skk = lane & 3;  // this lane's neighbour is column 4 sstep + skk
                         float* dst = nbf + (((sstep >> 1) * 4 + skk) * 8) + (sstep & 1);
                         dst[0] = sx; dst[2] = sy; dst[4] = sz; dst[6] = __uint_as_float(off);
+                        if constexpr (CUT) dn2 = real ? (sx * sx + sy * sy) + sz * sz : 3.4e38f;
+                    }
+                    int ncut = 64;
+                    if constexpr (CUT) {
+                        // sorted row: the columns inside the cutoff are a prefix of the chunk
+                        ncut = __builtin_popcountll(__ballot(dn2 <= cut2));
+                        if (ncut == 0 && (MODE == 0 || h0 > 0)) break;
                     }
                     wave_lds_order();
-                    const int cols = min(64, h - h0);
+                    const int cols = min(min(64, h - h0), ncut);
                     const int steps = (cols + 3) >> 2;
                     const int npairs = (steps + 1) >> 1;
                     constexpr int GP = GS >= 2 ? GS / 2 : 1;         // step pairs whose loads are in flight together
@@ -794,6 +842,19 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                         if (gi + 1 < ngroups) {
                             if (gi + 2 < ngroups) load_pairs(gi + 2, 0);
                             comp_pairs(1);
+                        }
+                    }
+                    if constexpr (CUT) {
+                        if (ncut < 64) break;                         // the row left the cutoff inside this chunk
+                        if constexpr (MODE == 2) {
+                            if (h0 == 0) {
+                                // from here on a neighbour matters only inside max(influence reach, what could still lower a minimum)
+                                float m = fminf(mind, __shfl_xor(mind, 16, 64));
+                                m = fminf(m, __shfl_xor(m, 32, 64));
+                                const float reach = group_max(haskp ? __builtin_sqrtf(m) + rk : 0.0f);
+                                const float R = fmaxf(rq, reach) * 1.0001f;
+                                cut2 = R * R;
+                            }
                         }
                     }
                     continue;
@@ -1203,7 +1264,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_kernel(
 // one float4 store (d x, d y, d z, d modulation) per kernel point.  Sums are per-lane partial sums combined by a fixed
 // shuffle tree: deterministic.
 // ---------------------------------------------------------------------------------------------
-template <int CK, bool AREG, typename T>
+template <int CK, bool AREG, typename T, bool CUT = false>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_def_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci, const T* __restrict__ dwf,
@@ -1259,16 +1320,23 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_def_kernel(
         };
         int idx; float px, py, pz;
         fetch(0, idx, px, py, pz);
+        float cut2 = 3.4e38f;                                     // CUT: see kpconv_gather_fwd_mfma_kernel (sorted rows)
         for (int h0 = 0; h0 < h; h0 += 64) {
             wave_lds_order();                                     // the previous chunk's readers are done
+            int ncut = 64;
             {
                 const bool incol = h0 + lane < h;                 // past the row: far beyond the shadow point (never the minimum)
-                nb[lane] = make_float4(incol ? px - qx : 3.0e18f, incol ? py - qy : 3.0e18f, incol ? pz - qz : 3.0e18f,
-                                       __int_as_float(idx));
+                const float ox = px - qx, oy = py - qy, oz = pz - qz;
+                nb[lane] = make_float4(incol ? ox : 3.0e18f, incol ? oy : 3.0e18f, incol ? oz : 3.0e18f, __int_as_float(idx));
+                if constexpr (CUT) {
+                    const float dn2 = (incol && idx >= 0) ? (ox * ox + oy * oy) + oz * oz : 3.4e38f;
+                    ncut = __builtin_popcountll(__ballot(dn2 <= cut2));
+                    if (ncut == 0 && h0 > 0) break;
+                }
             }
             wave_lds_order();
-            if (h0 + 64 < h) fetch(h0 + 64, idx, px, py, pz);     // next chunk's chain under this chunk's work
-            const int nblk = min(4, (h - h0 + 15) >> 4);
+            if (h0 + 64 < h && ncut == 64) fetch(h0 + 64, idx, px, py, pz);     // next chunk's chain under this chunk's work
+            const int nblk = min(4, (min(h - h0, ncut) + 15) >> 4);
             float bv[2][CK];
             float4 nv[2];
             auto load_b = [&](int b4, int slot) {
@@ -1323,6 +1391,29 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_def_kernel(
                 if (b4 < nblk) {
                     if (b4 + 1 < nblk) load_b(b4 + 1, (b4 + 1) & 1);
                     compute(b4, b4 & 1);
+                }
+            }
+            if constexpr (CUT) {
+                if (ncut < 64) break;                             // the row left the cutoff inside this chunk
+                if (h0 == 0) {
+                    // influence reach and what could still lower a minimum, over this query's 15 kernel points
+                    float reach = 0.0f, rq = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float bm = best[r];
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) bm = fminf(bm, __shfl_xor(bm, o, 64));
+                        if (4 * g + r < K) {
+                            const float rk = __builtin_sqrtf((kq[r].x * kq[r].x + kq[r].y * kq[r].y) + kq[r].z * kq[r].z);
+                            rq = fmaxf(rq, rk);
+                            reach = fmaxf(reach, __builtin_sqrtf(bm) + rk);
+                        }
+                    }
+                    float R = fmaxf(rq + extent, reach);
+                    R = fmaxf(R, __shfl_xor(R, 16, 64));
+                    R = fmaxf(R, __shfl_xor(R, 32, 64));
+                    R *= 1.0001f;
+                    cut2 = R * R;
                 }
             }
         }
@@ -1643,7 +1734,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
 // Summation order = order of the walk (a function of the grid alone): deterministic, equal to the transposed-table
 // form up to fp32 re-association.
 // ---------------------------------------------------------------------------------------------
-template <int K, int G, int MODE, bool VEC, typename T = float>
+template <int K, int G, int MODE, bool VEC, int NCH, typename T = float>
 __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
     const float* __restrict__ s_pts, int64_t ns, const CloudGrid* __restrict__ grids, int nb,
     const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
@@ -1653,7 +1744,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
 {
     constexpr int CC = 4 * G;
     constexpr int S = 64 / G;
-    constexpr int NCH = 4;
+    static_assert(NCH == 1 || NCH == 2 || NCH == 4, "channel chunks whose accumulators stay in registers");
     constexpr int SLAB = 192;
     __shared__ uint2 pool_all[4][POOL_ALLOC];
     __shared__ int segs_all[4][K + 1];
@@ -1670,9 +1761,20 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
     const float inv_extent = 1.0f / g.extent;
 
     float kpr[MODE == 0 ? 3 * K : 1];
+    // a pair farther apart than the reach of every kernel point (max |kp| + extent) carries no influence: it is no
+    // candidate, and an untruncated row (sorted by distance) is left at the first entry beyond it -- see CUT above
+    float cut2 = 3.4e38f;
     if (MODE == 0) {
 #pragma unroll
         for (int t = 0; t < 3 * K; ++t) kpr[t] = kernel_points[t];
+        float rr = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) rr = fmaxf(rr, (kpr[3 * k] * kpr[3 * k] + kpr[3 * k + 1] * kpr[3 * k + 1]) + kpr[3 * k + 2] * kpr[3 * k + 2]);
+        const float R = (__builtin_sqrtf(rr) + g.extent) * 1.0001f;
+        cut2 = R * R;
+    } else if (MODE == 2 && g.rmax) {
+        const float R = (g.rmax[0] + g.extent) * 1.0001f;
+        cut2 = R * R;
     }
 
     int64_t ibeg, iend;
@@ -1712,13 +1814,14 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
             int cnt = 0;
             // flush the pool into the accumulators of every channel chunk (balanced over the S slots)
             auto flush = [&](int total) {
-                wave_lds_sync();
+                wave_lds_order();
                 total = min(total, POOL);
                 const int per = (total + S - 1) / S;
                 const int lo = slot * per;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    if (cg0 + c * CC >= ci) break;                      // wave-uniform
+                    if (cg0 + c * CC >= ci) continue;                   // wave-uniform (no `break`: the loop must unroll, or
+                                                                        // the accumulators land in scratch memory)
                     const int chl = chok[c] ? cg0 + c * CC + 4 * j : 0;
                     const int hi = chok[c] ? min(lo + per, total) : lo;
                     for (int it = 0; it < per; it += 4) {
@@ -1746,13 +1849,114 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
                         }
                     }
                 }
-                wave_lds_sync();
+                wave_lds_order();
             };
-            // list + flush of the slab entries [base, base + 64) (entries >= cnt are dead lanes)
-            auto process = [&](int base) {
-                const int p = base + lane;
-                const bool real = p < cnt;
-                const float4 c = slab[real ? p : 0];
+            // membership of candidate c (the query) for this support: inside the radius and not cut off q's row
+            auto member = [&](const float4& c, bool active, unsigned long long kl) -> bool {
+                const float d2 = ref_d2(c.x, c.y, c.z, make_float4(sx, sy, sz, 0.0f));
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)s;
+                return active && d2 < r2 && d2 <= cut2 && key <= kl;
+            };
+            // ONE loop hands 64-pair batches to ONE inlined copy of the list / flush phases (a lambda that is called from
+            // several places is outlined, and everything it captures -- the accumulators, the kernel points -- then lives in
+            // scratch memory: the first form of this kernel ran 8 x slower than the transposed-table kernel for that reason).
+            //   from_row   the support's own (untruncated) row holds every point within the radius: nearly every entry is a
+            //              pair, the chunks go to the list phase directly.  The chain  row entry -> coordinates / key_last
+            //              of chunk i + 1 and the row entries of chunk i + 2 are in flight under the work of chunk i.
+            //   walk       the nine cell runs around the support, 128 candidates per step; hits are queued in the slab
+            //              (capacity 2 x 64 + a dummy slot per lane) and leave it 64 at a time.
+            const int nchunk = from_row ? (g.rows_h + 63) >> 6 : 0;
+            auto load_q = [&](int ch) -> int64_t {
+                const int col = 64 * ch + lane;
+                return (ch < nchunk && col < g.rows_h) ? g.rows[s * g.rows_h + col] : -1;
+            };
+            auto load_c = [&](int64_t qi, float4& c, unsigned long long& kl) -> bool {
+                const bool active = qi >= 0 && qi < ns;
+                const int64_t qq = active ? qi : 0;
+                c = make_float4(s_pts[3 * qq + 0], s_pts[3 * qq + 1], s_pts[3 * qq + 2], __int_as_float((int)qq));
+                kl = key_last[qq];
+                return active;
+            };
+            float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+            unsigned long long kl0 = 0, kl1 = 0;
+            bool a0 = false, a1 = false;
+            int64_t q1 = -1;
+            int ch = 0;
+            if (from_row) {
+                a0 = load_c(load_q(0), c0, kl0);
+                q1 = load_q(1);
+            }
+            int run = 0, rp = 0, re = 0;                       // walk state: next run, position / end inside the current run
+            if (!from_row && gr.s_len > 0) {
+                const int cx = cell_coord(sx, gr.lo[0], gr.inv_cell);
+                const int cy = cell_coord(sy, gr.lo[1], gr.inv_cell);
+                const int cz = cell_coord(sz, gr.lo[2], gr.inv_cell);
+                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gr.nx - 1);
+                if (lane < 9) {
+                    const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
+                    const bool ok = x0 <= x1 && z >= 0 && z < gr.nz && y >= 0 && y < gr.ny;
+                    const int row = gr.cell_base + ((ok ? z : 0) * gr.ny + (ok ? y : 0)) * gr.nx;
+                    runs[lane] = make_int2(ok ? cell_start[row + x0] : 0, ok ? cell_start[row + x1 + 1] : 0);
+                }
+                wave_lds_order();
+            } else {
+                run = 9;
+            }
+            for (;;) {
+                float4 c;
+                bool real;
+                if (from_row) {
+                    if (ch >= nchunk) break;
+                    {   // the row is sorted by distance: past the reach (or at the padding) nothing follows
+                        const float d2f = ref_d2(c0.x, c0.y, c0.z, make_float4(sx, sy, sz, 0.0f));
+                        const float d2_first = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(d2f)));
+                        const int a_first = __builtin_amdgcn_readfirstlane(a0 ? 1 : 0);
+                        if (!a_first || d2_first > cut2) break;
+                    }
+                    if (ch + 1 < nchunk) a1 = load_c(q1, c1, kl1);
+                    q1 = load_q(ch + 2);
+                    c = c0;
+                    real = member(c0, a0, kl0);
+                    c0 = c1; kl0 = kl1; a0 = a1; a1 = false;
+                    ++ch;
+                } else {
+                    // fill the queue up to 64 hits (or the end of the walk)
+                    while (cnt < 64) {
+                        if (rp >= re) {
+                            if (run >= 9) break;
+                            const int2 rr = runs[run++];
+                            rp = __builtin_amdgcn_readfirstlane(rr.x);
+                            re = __builtin_amdgcn_readfirstlane(rr.y);
+                            continue;
+                        }
+                        const int pa = rp + lane, pb = rp + 64 + lane;
+                        const bool aa = pa < re, ab = pb < re;
+                        const float4 ca = sorted[aa ? pa : rp], cb = sorted[ab ? pb : rp];
+                        const unsigned long long ka = key_last[__float_as_int(ca.w)], kb = key_last[__float_as_int(cb.w)];
+                        const bool ha = member(ca, aa, ka), hb = member(cb, ab, kb);
+                        const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+                        const int na = __builtin_popcountll(ma);
+                        slab[ha ? cnt + lane_rank(ma) : SLAB + lane] = ca;          // cnt < 64 on entry: both batches fit 192
+                        slab[hb ? cnt + na + lane_rank(mb) : SLAB + lane] = cb;
+                        cnt += na + __builtin_popcountll(mb);
+                        rp += 128;
+                    }
+                    if (cnt == 0) break;
+                    wave_lds_order();
+                    const int take_n = min(cnt, 64);
+                    real = lane < take_n;
+                    c = slab[real ? lane : 0];
+                    // the remainder (< 128 entries) moves to the front
+                    const int rem = cnt - take_n;
+                    const float4 t0 = slab[64 + (lane < rem ? lane : 0)];
+                    const float4 t1 = slab[128 + (lane + 64 < rem ? lane : 0)];
+                    wave_lds_order();
+                    if (lane < rem) slab[lane] = t0;
+                    if (lane + 64 < rem) slab[64 + lane] = t1;
+                    cnt = rem;
+                    wave_lds_order();
+                }
+                // ---- list + flush of this batch: lane = pair (c = the query's coordinates and index; !real = dead lane)
                 const int q = real ? __float_as_int(c.w) : 0;
                 const float nx = sx - c.x, ny = sy - c.y, nz = sz - c.z;
                 int total = 0, maxlen = 0;
@@ -1787,63 +1991,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
                         }
                     }
                 }
-            };
-            // candidates enter through here; when fewer than 64 free slots remain the full batches are consumed
-            auto take = [&](const float4& c, bool active) {
-                const float d2 = ref_d2(c.x, c.y, c.z, make_float4(sx, sy, sz, 0.0f));
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)s;
-                bool hit = active && d2 < r2;
-                hit = hit && key <= key_last[hit ? __float_as_int(c.w) : 0];
-                const unsigned long long m = __ballot(hit);
-                const int pos = cnt + lane_rank(m);
-                slab[hit ? pos : SLAB + lane] = c;                  // pos < SLAB: cnt <= SLAB - 64 on entry
-                cnt += __builtin_popcountll(m);
-                if (cnt > SLAB - 64) {
-                    wave_lds_sync();
-                    int base = 0;
-                    for (; base + 64 <= cnt; base += 64) process(base);
-                    const int rem = cnt - base;
-                    const float4 t = slab[base + (lane < rem ? lane : 0)];
-                    wave_lds_sync();
-                    if (lane < rem) slab[lane] = t;
-                    cnt = rem;
-                    wave_lds_sync();
-                }
-            };
-            if (from_row) {
-                for (int h0 = 0; h0 < g.rows_h; h0 += 64) {
-                    const int col = h0 + lane;
-                    const int64_t qi = col < g.rows_h ? g.rows[s * g.rows_h + col] : -1;
-                    const bool active = qi >= 0 && qi < ns;
-                    const int64_t qq = active ? qi : 0;
-                    take(make_float4(s_pts[3 * qq + 0], s_pts[3 * qq + 1], s_pts[3 * qq + 2], __int_as_float((int)qq)), active);
-                }
-            } else if (gr.s_len > 0) {
-                const int cx = cell_coord(sx, gr.lo[0], gr.inv_cell);
-                const int cy = cell_coord(sy, gr.lo[1], gr.inv_cell);
-                const int cz = cell_coord(sz, gr.lo[2], gr.inv_cell);
-                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gr.nx - 1);
-                if (lane < 9) {
-                    const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
-                    const bool ok = x0 <= x1 && z >= 0 && z < gr.nz && y >= 0 && y < gr.ny;
-                    const int row = gr.cell_base + ((ok ? z : 0) * gr.ny + (ok ? y : 0)) * gr.nx;
-                    runs[lane] = make_int2(ok ? cell_start[row + x0] : 0, ok ? cell_start[row + x1 + 1] : 0);
-                }
-                wave_lds_sync();
-                for (int r = 0; r < 9; ++r) {
-                    const int2 run = runs[r];
-                    const int rb = __builtin_amdgcn_readfirstlane(run.x), re = __builtin_amdgcn_readfirstlane(run.y);
-                    for (int p0 = rb; p0 < re; p0 += 64) {
-                        const int p = p0 + lane;
-                        take(sorted[p < re ? p : rb], p < re);
-                    }
-                }
             }
-            wave_lds_sync();
-            for (int base = 0; base < cnt; base += 64) process(base);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (cg0 + c * CC >= ci) break;
+                if (cg0 + c * CC >= ci) continue;
 #pragma unroll
                 for (int o = G; o < 64; o <<= 1) {
                     acc[c].x += __shfl_xor(acc[c].x, o, 64);
@@ -1869,7 +2020,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
                     }
                 }
             }
-            wave_lds_sync();
+            wave_lds_order();
         }
     }
 }
@@ -1896,14 +2047,15 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
                     const int64_t* inds, int32_t h, const T* x, int32_t ci,
                     const float* kernel_points, int32_t k, const float* deformed_kp,
                     const float* modulations, float extent, int32_t influence, int32_t aggregation,
-                    const int32_t* order, T* wf, float* min_d2, void* stream)
+                    const int32_t* order, T* wf, float* min_d2, void* stream, int rows_sorted = 0)
 {
     constexpr bool F32 = sizeof(T) == 4;
     int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, influence, aggregation);
     if (rc) return rc;
     if (nq == 0) return WS_OK;
     WS_REQUIRE(inds && x && wf && (kernel_points || deformed_kp), "NULL argument");
-    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, nullptr, 0.0f, nullptr, 0};
+    GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, nullptr, 0.0f, nullptr, 0, nullptr, nullptr,
+                 rows_sorted ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(nq, 4);
     WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
@@ -1935,6 +2087,9 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
 #define WS_FWDM(NTV)                                    \
     do {                                                \
         if (deformed_kp) WS_FWDM2(NTV, 1, true);        \
+        else if (fastm && rows_sorted)                  \
+            kpconv_gather_fwd_mfma_kernel<NTV, 0, false, true, T, 0, true><<<grid, 256, 0, st>>>(                      \
+                q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points, deformed_kp, modulations, g, wf, min_d2, order);  \
         else if (fastm) WS_FWDM2(NTV, 0, false);        \
         else WS_FWDM2(NTV, 1, false);                   \
     } while (0)
@@ -2112,7 +2267,7 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
 template <typename T>
 int gather_fwd_def_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
                         const T* x, int32_t ci, const float4* kp4, int32_t k, float extent, const int32_t* order, T* wf,
-                        float* min_d2, void* stream)
+                        float* min_d2, void* stream, int rows_sorted)
 {
     int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM);
     if (rc) return rc;
@@ -2126,9 +2281,15 @@ int gather_fwd_def_impl(const float* q_pts, int64_t nq, const float* s_pts, int6
     int nt = ci <= 16 ? 1 : (ci <= 32 ? 2 : (ci <= 64 ? 4 : (ci <= 128 ? 8 : 16)));
     if (!((ci % nt == 0) && (nt == 1 || (aligned16(x) && aligned16(wf))))) nt = 1;
     if (sizeof(T) == 2 && nt == 1 && (ci % 2)) return ws_fail(WS_ERR_UNSUPPORTED, "bf16 rows need an even channel count (ci=%d)", ci);
-#define WS_FWDD(NTV) \
-    kpconv_gather_fwd_mfma_kernel<NTV, 2, true, true, T><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, nullptr, nullptr, \
-                                                                              nullptr, g, wf, min_d2, order)
+#define WS_FWDD(NTV)                                                                                                     \
+    do {                                                                                                                 \
+        if (rows_sorted)                                                                                                 \
+            kpconv_gather_fwd_mfma_kernel<NTV, 2, true, true, T, 0, true><<<grid, 256, 0, st>>>(                          \
+                q_pts, nq, s_pts, ns, inds, h, x, ci, nullptr, nullptr, nullptr, g, wf, min_d2, order);                   \
+        else                                                                                                             \
+            kpconv_gather_fwd_mfma_kernel<NTV, 2, true, true, T><<<grid, 256, 0, st>>>(                                   \
+                q_pts, nq, s_pts, ns, inds, h, x, ci, nullptr, nullptr, nullptr, g, wf, min_d2, order);                   \
+    } while (0)
     if (nt == 1) WS_FWDD(1);
     else if (nt == 2) WS_FWDD(2);
     else if (nt == 4) WS_FWDD(4);
@@ -2178,7 +2339,7 @@ template <typename T>
 int gather_bwd_x_gridw_impl(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
                             const uint64_t* key_last, float radius, const T* dwf, int32_t ci, const float* kernel_points,
                             int32_t k, const float4* kp4, float extent, const int32_t* order, const int64_t* rows, int32_t rows_h,
-                            T* dx, void* stream)
+                            T* dx, void* stream, const float* rmax)
 {
     constexpr bool F32 = sizeof(T) == 4;
     int rc = check_common(s_pts, ns, s_pts, ns, 1, ci, k, extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM);
@@ -2190,7 +2351,7 @@ int gather_bwd_x_gridw_impl(const float* s_pts, int64_t ns, const void* grid_blo
     WS_REQUIRE(ns * (int64_t)k * ci < (1ll << 31), "ns*k*ci exceeds the 32-bit row offsets of the gather");
     WS_REQUIRE(!rows || rows_h >= 1, "index rows given without their width");
     GeomParams g{extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, kp4 ? 1 : 0, 0, nullptr, 0.0f,
-                 ws_kpconv_grid_rows ? rows : nullptr, rows_h, kp4};
+                 ws_kpconv_grid_rows ? rows : nullptr, rows_h, kp4, kp4 ? rmax : nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
     const char* base = (const char*)grid_blob;
     const CloudGrid* grids = (const CloudGrid*)base;
@@ -2201,11 +2362,18 @@ int gather_bwd_x_gridw_impl(const float* s_pts, int64_t ns, const void* grid_blo
     const int grid = ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
     WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
+#define WS_GW3(G, MODEV, VECV, NCHV)                                                                                  \
+    kpconv_gather_bwd_x_gridw_kernel<15, G, MODEV, VECV, NCHV, T><<<grid, 256, 0, st>>>(                              \
+        s_pts, ns, grids, nb, cell_start, sorted, kl, r2, dwf, ci, kernel_points, nullptr, nullptr, g, dx, order)
 #define WS_GW2(G, MODEV, VECV)                                                                                        \
     do {                                                                                                              \
-        if constexpr (F32 || VECV)                                                                                    \
-            kpconv_gather_bwd_x_gridw_kernel<15, G, MODEV, VECV, T><<<grid, 256, 0, st>>>(                             \
-                s_pts, ns, grids, nb, cell_start, sorted, kl, r2, dwf, ci, kernel_points, nullptr, nullptr, g, dx, order); \
+        if constexpr (F32 || VECV) {                                                                                  \
+            if (G < 16 || ci <= 64) WS_GW3(G, MODEV, VECV, 1);                                                        \
+            else if constexpr (G == 16) {                                                                             \
+                if (ci <= 128) WS_GW3(G, MODEV, VECV, 2);                                                             \
+                else WS_GW3(G, MODEV, VECV, 4);                                                                       \
+            }                                                                                                         \
+        }                                                                                                             \
     } while (0)
 #define WS_GW(G)                                                                        \
     do {                                                                                \
@@ -2217,6 +2385,7 @@ int gather_bwd_x_gridw_impl(const float* s_pts, int64_t ns, const void* grid_blo
     else if (ci <= 16) WS_GW(4);
     else if (ci <= 32) WS_GW(8);
     else WS_GW(16);
+#undef WS_GW3
 #undef WS_GW2
 #undef WS_GW
     WS_LAUNCH_CHECK();
@@ -2226,7 +2395,7 @@ int gather_bwd_x_gridw_impl(const float* s_pts, int64_t ns, const void* grid_blo
 template <typename T>
 int gather_bwd_geom_def_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
                              const T* x, int32_t ci, const T* dwf, const float4* kp4, int32_t k, const float* d_min_d2,
-                             float extent, const int32_t* order, float4* d_kp4, void* stream)
+                             float extent, const int32_t* order, float4* d_kp4, void* stream, int rows_sorted)
 {
     int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM);
     if (rc) return rc;
@@ -2237,9 +2406,15 @@ int gather_bwd_geom_def_impl(const float* q_pts, int64_t nq, const float* s_pts,
         return ws_fail(WS_ERR_UNSUPPORTED, "geometry backward on the matrix core needs ci %% 16 == 0 and 16-byte aligned rows (ci=%d)", ci);
     hipStream_t st = (hipStream_t)stream;
     const int grid = ws_grid(nq, 4);
-#define WS_K6(CKV, AREGV) \
-    kpconv_gather_bwd_geom_def_kernel<CKV, AREGV, T><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf, kp4, d_min_d2, \
-                                                                           extent, d_kp4, order)
+#define WS_K6(CKV, AREGV)                                                                                                 \
+    do {                                                                                                                  \
+        if (rows_sorted)                                                                                                  \
+            kpconv_gather_bwd_geom_def_kernel<CKV, AREGV, T, true><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf, kp4, \
+                                                                                         d_min_d2, extent, d_kp4, order); \
+        else                                                                                                              \
+            kpconv_gather_bwd_geom_def_kernel<CKV, AREGV, T, false><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf, kp4, \
+                                                                                          d_min_d2, extent, d_kp4, order); \
+    } while (0)
     if (ci == 16) WS_K6(4, true);
     else if (ci == 32) WS_K6(8, true);
     else if (ci == 64) WS_K6(16, true);
@@ -2262,12 +2437,29 @@ extern "C" {
 //      (x, wf, dwf, dx) are bf16 instead of f32.
 int ws_kpconv_gather_fwd_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
                              const void* x, int32_t ci, const float* kp4, int32_t k, float extent, const int32_t* order,
-                             void* wf, float* min_d2, int32_t rows_bf16, void* stream)
+                             void* wf, float* min_d2, int32_t rows_bf16, int32_t rows_sorted, void* stream)
 {
     const float4* kq = reinterpret_cast<const float4*>(kp4);
     if (rows_bf16)
-        return gather_fwd_def_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, (const bf16_t*)x, ci, kq, k, extent, order, (bf16_t*)wf, min_d2, stream);
-    return gather_fwd_def_impl<float>(q_pts, nq, s_pts, ns, inds, h, (const float*)x, ci, kq, k, extent, order, (float*)wf, min_d2, stream);
+        return gather_fwd_def_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, (const bf16_t*)x, ci, kq, k, extent, order, (bf16_t*)wf, min_d2,
+                                           stream, rows_sorted);
+    return gather_fwd_def_impl<float>(q_pts, nq, s_pts, ns, inds, h, (const float*)x, ci, kq, k, extent, order, (float*)wf, min_d2, stream,
+                                      rows_sorted);
+}
+
+// ws_kpconv_gather_fwd / _bf16 for index rows that are sorted by distance from their query (rows_sorted != 0: what the radius
+// search delivers): the rigid linear / sum forms then stop at the reach of the kernel points (see CUT above); other modes and
+// rows_sorted == 0 are the plain entries.
+int ws_kpconv_gather_fwd_ex(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                            const void* x, int32_t ci, const float* kernel_points, int32_t k, const float* deformed_kp,
+                            const float* modulations, float extent, int32_t influence, int32_t aggregation, const int32_t* order,
+                            void* wf, float* min_d2, int32_t rows_bf16, int32_t rows_sorted, void* stream)
+{
+    if (rows_bf16)
+        return gather_fwd_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, (const bf16_t*)x, ci, kernel_points, k, deformed_kp, modulations,
+                                       extent, influence, aggregation, order, (bf16_t*)wf, min_d2, stream, rows_sorted);
+    return gather_fwd_impl<float>(q_pts, nq, s_pts, ns, inds, h, (const float*)x, ci, kernel_points, k, deformed_kp, modulations, extent,
+                                  influence, aggregation, order, (float*)wf, min_d2, stream, rows_sorted);
 }
 
 int ws_kpconv_gather_bwd_x_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, int32_t h,
@@ -2283,28 +2475,30 @@ int ws_kpconv_gather_bwd_x_def(const float* q_pts, int64_t nq, const float* s_pt
 // the table-free backward for any in-degree (rows wider than 128): rigid (kp4 NULL, kernel_points given) or deformable (kp4)
 int ws_kpconv_gather_bwd_x_grid_wide(const float* s_pts, int64_t ns, const void* grid_blob, int32_t nb, int64_t cells,
                                      const uint64_t* key_last, float radius, const void* dwf, int32_t ci,
-                                     const float* kernel_points, int32_t k, const float* kp4, float extent, const int32_t* order,
-                                     const int64_t* rows, int32_t rows_h, void* dx, int32_t rows_bf16, void* stream)
+                                     const float* kernel_points, int32_t k, const float* kp4, const float* kp_rmax, float extent,
+                                     const int32_t* order, const int64_t* rows, int32_t rows_h, void* dx, int32_t rows_bf16,
+                                     void* stream)
 {
     const float4* kq = reinterpret_cast<const float4*>(kp4);
     if (rows_bf16)
         return gather_bwd_x_gridw_impl<bf16_t>(s_pts, ns, grid_blob, nb, cells, key_last, radius, (const bf16_t*)dwf, ci, kernel_points, k,
-                                               kq, extent, order, rows, rows_h, (bf16_t*)dx, stream);
+                                               kq, extent, order, rows, rows_h, (bf16_t*)dx, stream, kp_rmax);
     return gather_bwd_x_gridw_impl<float>(s_pts, ns, grid_blob, nb, cells, key_last, radius, (const float*)dwf, ci, kernel_points, k, kq,
-                                          extent, order, rows, rows_h, (float*)dx, stream);
+                                          extent, order, rows, rows_h, (float*)dx, stream, kp_rmax);
 }
 
 int ws_kpconv_gather_bwd_geom_def(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
                                   const void* x, int32_t ci, const void* dwf, const float* kp4, int32_t k, const float* d_min_d2,
-                                  float extent, const int32_t* order, float* d_kp4, int32_t rows_bf16, void* stream)
+                                  float extent, const int32_t* order, float* d_kp4, int32_t rows_bf16, int32_t rows_sorted,
+                                  void* stream)
 {
     const float4* kq = reinterpret_cast<const float4*>(kp4);
     float4* dk = reinterpret_cast<float4*>(d_kp4);
     if (rows_bf16)
         return gather_bwd_geom_def_impl<bf16_t>(q_pts, nq, s_pts, ns, inds, h, (const bf16_t*)x, ci, (const bf16_t*)dwf, kq, k, d_min_d2,
-                                                extent, order, dk, stream);
+                                                extent, order, dk, stream, rows_sorted);
     return gather_bwd_geom_def_impl<float>(q_pts, nq, s_pts, ns, inds, h, (const float*)x, ci, (const float*)dwf, kq, k, d_min_d2, extent,
-                                           order, dk, stream);
+                                           order, dk, stream, rows_sorted);
 }
 
 int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,

@@ -162,6 +162,24 @@ def set_search_grids(pairs):
         _grids[(inds.data_ptr(), tuple(inds.shape))] = (inds, grid)
 
 
+_sorted_rows = set()
+
+
+def set_sorted_rows(mats):
+    """index matrices whose rows are sorted by distance from the query (the output of the radius search): installed by
+    PyramidBatch.activate for the batch about to be trained on.  The linear-influence gather kernels then stop each row at the
+    reach of the kernel points (exact: the skipped influences are zeros; include/weasal_hip.h `rows_sorted`)."""
+    _sorted_rows.clear()
+    for m in mats:
+        if isinstance(m, torch.Tensor) and m.dim() == 2 and m.shape[0] > 0:
+            _sorted_rows.add((m.data_ptr(), tuple(m.shape)))
+
+
+def rows_are_sorted(inds):
+    return SORTED_ROW_CUTOFF and (inds.data_ptr(), tuple(inds.shape)) in _sorted_rows
+
+
+SORTED_ROW_CUTOFF = os.environ.get("WEASAL_ROW_CUTOFF", "1") != "0"      # A/B switch (diagnostics, tests)
 GRID_NARROW_MAX = 128      # rows up to this length: the slab form of the grid backward (ws_kpconv_gather_bwd_x_grid); wider: _wide
 
 
@@ -185,7 +203,7 @@ class _KPConvGather(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, deformed_kp, modulations, q_pts, s_pts, inds, kernel_points, extent, influence,
-                aggregation, want_min_d2):
+                aggregation, want_min_d2, rows_sorted=False):
         lib = _lib.lib()
         _need_cuda(x, q_pts, s_pts, inds, kernel_points)
         x = x.contiguous()
@@ -200,11 +218,16 @@ class _KPConvGather(torch.autograd.Function):
         dkp = deformed_kp.float().contiguous() if deformed_kp is not None else None
         mod = modulations.float().contiguous() if modulations is not None else None
         tok = _tbegin("kpconv_gather_fwd", nq, h, ci)
-        fwd = lib.ws_kpconv_gather_fwd_bf16 if bf else lib.ws_kpconv_gather_fwd
-        check(fwd(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci,
-                                       ptr(kernel_points), k, ptr(dkp), ptr(mod), float(extent),
-                                       influence, aggregation, ptr(_order_for(q_pts)), ptr(wf), ptr(min_d2),
-                                       current_stream()))
+        if rows_sorted:
+            check(lib.ws_kpconv_gather_fwd_ex(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(kernel_points), k, ptr(dkp),
+                                              ptr(mod), float(extent), influence, aggregation, ptr(_order_for(q_pts)), ptr(wf),
+                                              ptr(min_d2), 1 if bf else 0, 1, current_stream()))
+        else:
+            fwd = lib.ws_kpconv_gather_fwd_bf16 if bf else lib.ws_kpconv_gather_fwd
+            check(fwd(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci,
+                                           ptr(kernel_points), k, ptr(dkp), ptr(mod), float(extent),
+                                           influence, aggregation, ptr(_order_for(q_pts)), ptr(wf), ptr(min_d2),
+                                           current_stream()))
         _tend(tok)
         ctx.save_for_backward(x, dkp, mod, q_pts, s_pts, inds, kernel_points)
         ctx.cfg = (float(extent), influence, aggregation)
@@ -233,7 +256,7 @@ class _KPConvGather(torch.autograd.Function):
                 grid = None          # the queue form of the grid backward covers linear / sum only: transposed table
             if grid is not None and grid.ns == ns and wide:
                 check(lib.ws_kpconv_gather_bwd_x_grid_wide(ptr(s_pts), ns, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last),
-                                                           grid.radius, ptr(dwf), ci, ptr(kernel_points), k, None, extent,
+                                                           grid.radius, ptr(dwf), ci, ptr(kernel_points), k, None, None, extent,
                                                            ptr(_order_for(s_pts)), ptr(inds), h, ptr(dx), 1 if bf else 0,
                                                            current_stream()))
             elif grid is not None and grid.ns == ns:
@@ -257,12 +280,13 @@ class _KPConvGather(torch.autograd.Function):
             check(f_geom(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(dwf),
                                                 ptr(kernel_points), k, ptr(dkp), ptr(mod), ptr(dmin), extent,
                                                 influence, aggregation, ptr(d_dkp), ptr(d_mod), current_stream()))
-        return dx, d_dkp, d_mod, None, None, None, None, None, None, None, None
+        return dx, d_dkp, d_mod, None, None, None, None, None, None, None, None, None
 
 
 def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linear", aggregation="sum",
-                  deformed_kp=None, modulations=None, want_min_d2=False):
-    """Fused neighbour gather + kernel-point influence + aggregate -> wf [nq, K, ci] (and min_d2)."""
+                  deformed_kp=None, modulations=None, want_min_d2=False, rows_sorted=False):
+    """Fused neighbour gather + kernel-point influence + aggregate -> wf [nq, K, ci] (and min_d2).
+    rows_sorted: the rows of `inds` are sorted by distance from their query (see set_sorted_rows)."""
     q_pts = _f32c(q_pts)
     s_pts = _f32c(s_pts)
     kernel_points = _f32c(kernel_points)
@@ -270,7 +294,7 @@ def kpconv_gather(x, q_pts, s_pts, inds, kernel_points, extent, influence="linea
     if inds.dtype != torch.int64:
         inds = inds.to(torch.int64)
     return _KPConvGather.apply(x, deformed_kp, modulations, q_pts, s_pts, inds, kernel_points, extent,
-                               INFLUENCE[influence], AGGREGATION[aggregation], want_min_d2)
+                               INFLUENCE[influence], AGGREGATION[aggregation], want_min_d2, bool(rows_sorted))
 
 
 _KPCONV_GATHER_SELF = kpconv_gather      # (oracle.kpconv_ref.cpu_reference_mode swaps ops.kpconv_gather: then no fast paths)
@@ -293,15 +317,16 @@ class _DeformPrepare(torch.autograd.Function):
         kp4 = torch.empty((n, k, 4), dtype=torch.float32, device=off.device)
         dkp = torch.empty((n, k, 3), dtype=torch.float32, device=off.device)
         mod = torch.empty((n, k), dtype=torch.float32, device=off.device) if modulated else None
+        rmax = torch.empty((1,), dtype=torch.float32, device=off.device)
         check(lib.ws_kpconv_deform_prepare(ptr(off), n, od, ptr(kernel_points), k, float(extent), 1 if modulated else 0,
-                                           ptr(dkp), ptr(mod), ptr(kp4), current_stream()))
+                                           ptr(dkp), ptr(mod), ptr(kp4), ptr(rmax), current_stream()))
         ctx.save_for_backward(kp4)
         ctx.cfg = (n, od, k, float(extent), bool(modulated))
-        ctx.mark_non_differentiable(*([mod] if mod is not None else []))
-        return kp4, dkp, mod
+        ctx.mark_non_differentiable(rmax, *([mod] if mod is not None else []))
+        return kp4, dkp, mod, rmax
 
     @staticmethod
-    def backward(ctx, d_kp4, d_dkp, d_mod):
+    def backward(ctx, d_kp4, d_dkp, d_mod, d_rmax):
         lib = _lib.lib()
         kp4, = ctx.saved_tensors
         n, od, k, extent, modulated = ctx.cfg
@@ -316,8 +341,8 @@ class _DeformPrepare(torch.autograd.Function):
 
 
 def deform_prepare(offset_features, kernel_points, extent, modulated):
-    """-> (kp4, deformed_kp, modulations or None); `modulations` is a plain copy for the module attribute (its gradient
-    travels through kp4)"""
+    """-> (kp4, deformed_kp, modulations or None, kp_rmax); `modulations` is a plain copy for the module attribute (its
+    gradient travels through kp4); kp_rmax [1] = max |deformed kernel point| (device scalar for the grid backward)"""
     return _DeformPrepare.apply(offset_features, _f32c(kernel_points), float(extent), bool(modulated))
 
 
@@ -332,7 +357,7 @@ class _KPConvGatherDef(torch.autograd.Function):
     (models/blocks.py:278-367 for deformable = True, KP_influence = 'linear', aggregation_mode = 'sum')"""
 
     @staticmethod
-    def forward(ctx, x, kp4, q_pts, s_pts, inds, extent):
+    def forward(ctx, x, kp4, q_pts, s_pts, inds, extent, rmax, rows_sorted):
         lib = _lib.lib()
         _need_cuda(x, kp4, q_pts, s_pts, inds)
         x = x.contiguous()
@@ -345,17 +370,20 @@ class _KPConvGatherDef(torch.autograd.Function):
         min_d2 = torch.empty((nq, k), dtype=torch.float32, device=x.device)
         tok = _tbegin("kpconv_gather_fwd", nq, h, ci)
         check(lib.ws_kpconv_gather_fwd_def(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(kp4), k, float(extent),
-                                           ptr(_order_for(q_pts)), ptr(wf), ptr(min_d2), 1 if bf else 0, current_stream()))
+                                           ptr(_order_for(q_pts)), ptr(wf), ptr(min_d2), 1 if bf else 0, 1 if rows_sorted else 0,
+                                           current_stream()))
         _tend(tok)
-        ctx.save_for_backward(x, kp4, q_pts, s_pts, inds)
+        ctx.save_for_backward(x, kp4, q_pts, s_pts, inds, rmax)
         ctx.extent = float(extent)
+        ctx.rows_sorted = bool(rows_sorted)
         return wf, min_d2
 
     @staticmethod
     def backward(ctx, dwf, d_min_d2):
         lib = _lib.lib()
-        x, kp4, q_pts, s_pts, inds = ctx.saved_tensors
+        x, kp4, q_pts, s_pts, inds, rmax = ctx.saved_tensors
         extent = ctx.extent
+        rs = 1 if ctx.rows_sorted else 0
         nq, h = inds.shape
         ns, ci = x.shape
         k = kp4.shape[1]
@@ -368,7 +396,7 @@ class _KPConvGatherDef(torch.autograd.Function):
             tok = _tbegin("kpconv_gather_bwd_x", nq, h, ci)
             if grid is not None and grid.ns == ns:
                 check(lib.ws_kpconv_gather_bwd_x_grid_wide(ptr(s_pts), ns, ptr(grid.blob), grid.nb, grid.cells, ptr(grid.key_last),
-                                                           grid.radius, ptr(dwf), ci, None, k, ptr(kp4), extent,
+                                                           grid.radius, ptr(dwf), ci, None, k, ptr(kp4), ptr(rmax), extent,
                                                            ptr(_order_for(s_pts)), ptr(inds), h, ptr(dx), bf, current_stream()))
             else:
                 table = transposed_table(inds, ns)
@@ -381,17 +409,18 @@ class _KPConvGatherDef(torch.autograd.Function):
             dmin = d_min_d2.float().contiguous() if d_min_d2 is not None else None
             tok = _tbegin("kpconv_gather_bwd_geom", nq, h, ci)
             check(lib.ws_kpconv_gather_bwd_geom_def(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(dwf), ptr(kp4), k,
-                                                    ptr(dmin), extent, ptr(_order_for(q_pts)), ptr(d_kp4), bf, current_stream()))
+                                                    ptr(dmin), extent, ptr(_order_for(q_pts)), ptr(d_kp4), bf, rs, current_stream()))
             _tend(tok)
-        return dx, d_kp4, None, None, None, None
+        return dx, d_kp4, None, None, None, None, None, None
 
 
-def kpconv_gather_def(x, kp4, q_pts, s_pts, inds, extent):
-    """deformable fast path: -> (wf [nq,K,ci], min_d2 [nq,K])"""
+def kpconv_gather_def(x, kp4, q_pts, s_pts, inds, extent, kp_rmax=None, rows_sorted=False):
+    """deformable fast path: -> (wf [nq,K,ci], min_d2 [nq,K]); kp_rmax: deform_prepare's device scalar (bounds the grid
+    backward's candidates); rows_sorted: see set_sorted_rows"""
     inds = inds.contiguous()
     if inds.dtype != torch.int64:
         inds = inds.to(torch.int64)
-    return _KPConvGatherDef.apply(x, kp4, _f32c(q_pts), _f32c(s_pts), inds, float(extent))
+    return _KPConvGatherDef.apply(x, kp4, _f32c(q_pts), _f32c(s_pts), inds, float(extent), kp_rmax, bool(rows_sorted))
 
 
 class _P2PRegularizer(torch.autograd.Function):

@@ -243,6 +243,7 @@ class PyramidBatch:
                         t.record_stream(stream)
                 self.ready = None
             ops.set_point_orders(self.point_orders)
+            ops.set_sorted_rows(self.neighbors + self.pools)      # rows as the radius search wrote them: sorted by distance
             ops.set_search_grids(self.search_grids)
             ops.clear_table_cache()              # tables belong to one batch
             ops.install_tables(self.tables, self.col0_tables)
