@@ -428,6 +428,8 @@ typedef struct ws_kpblock {
      * parameter is NULL; the shortcut bias gradient equals db2) */
     const float* dout; float* dfeat; float *dw1, *db1, *dwk, *dbk, *dw2, *db2, *dws;
     int32_t timed;                       /* 1: bracket the K3 launch with HIP events (ws_timer_*) */
+    int32_t rows_sorted;                 /* 1: the rows of inds are sorted by distance from their query (radius search output):
+                                            the gather stops at the reach of the kernel points (ws_kpconv_gather_fwd_ex) */
 } ws_kpblock;
 
 int64_t ws_kpblock_fwd_scratch_bytes(const ws_kpblock* d);

@@ -126,7 +126,7 @@ class KPConv(nn.Module):
 
         # index rows known to be sorted by distance (a matrix of the batch's pyramid): the linear-influence kernels stop at
         # the reach of the kernel points
-        rows_sorted = (x.is_cuda and ops.rows_are_sorted(neighb_inds)) if _rows_sorted is None else _rows_sorted
+        rows_sorted = (x.is_cuda and ops.rows_cutoff_pays(neighb_inds, self.radius)) if _rows_sorted is None else _rows_sorted
         deformed = None
         modulations = None
         if self.deformable and DEFORM_FAST_PATH and ops.deform_fast_path_ok(x, self.K, self.KP_influence, self.aggregation_mode):

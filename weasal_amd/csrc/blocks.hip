@@ -166,8 +166,8 @@ int kpblock_fwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         rec.nq = nq; rec.h = d->h; rec.ci = d->conv_in;
         WS_HIP(hipEventRecord(rec.a, st));
     }
-    WS_TRY(ws_kpconv_gather_fwd(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, x1, d->conv_in, d->kernel_points, d->k, nullptr, nullptr,
-                                d->extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, d->order_q, d->wf, nullptr, st));
+    WS_TRY(ws_kpconv_gather_fwd_ex(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, x1, d->conv_in, d->kernel_points, d->k, nullptr, nullptr,
+                                   d->extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, d->order_q, d->wf, nullptr, 0, d->rows_sorted, st));
     if (d->timed) WS_HIP(hipEventRecord(rec.b, st));
     float* x2 = d->w2 ? d->x2 : d->out;
     WS_TRY(ws_gemm_xb_epilogue_strided(d->wf, nq, d->k * d->conv_in, (int64_t)d->k * d->conv_in, d->wk, d->conv_out, 1, d->conv_out,

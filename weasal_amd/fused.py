@@ -48,7 +48,7 @@ class KPBlockDesc(C.Structure):
                 ("w1", _vp), ("b1", _vp), ("wk", _vp), ("bk", _vp), ("w2", _vp), ("b2", _vp), ("ws", _vp), ("bs", _vp),
                 ("feat", _vp), ("x1", _vp), ("wf", _vp), ("x2", _vp), ("pooled", _vp), ("arg", _vp), ("out", _vp),
                 ("dout", _vp), ("dfeat", _vp), ("dw1", _vp), ("db1", _vp), ("dwk", _vp), ("dbk", _vp), ("dw2", _vp),
-                ("db2", _vp), ("dws", _vp), ("timed", _i32)]
+                ("db2", _vp), ("dws", _vp), ("timed", _i32), ("rows_sorted", _i32)]
 
 
 class UpUnaryDesc(C.Structure):
@@ -104,7 +104,7 @@ def _scratch(nbytes, device):
 class _Geom:
     """geometry + widths of one block call (plain Python object carried through the autograd node)"""
     __slots__ = ("q_pts", "s_pts", "inds", "kp", "extent", "order_q", "order_s", "grid", "table", "in_dim", "conv_in",
-                 "conv_out", "out_dim", "strided", "slope", "has")
+                 "conv_out", "out_dim", "strided", "slope", "has", "rows_sorted")
 
     def fill(self, d):
         d.q_pts, d.nq = self.q_pts.data_ptr(), self.q_pts.shape[0]
@@ -120,6 +120,7 @@ class _Geom:
             d.t_offsets, d.t_pairs = self.table.offsets.data_ptr(), self.table.pairs.data_ptr()
         d.in_dim, d.conv_in, d.conv_out, d.out_dim = self.in_dim, self.conv_in, self.conv_out, self.out_dim
         d.strided, d.slope = 1 if self.strided else 0, float(self.slope)
+        d.rows_sorted = 1 if self.rows_sorted else 0
 
 
 def _al(n):
@@ -225,6 +226,7 @@ def _geometry(conv, q_pts, s_pts, inds, strided):
     g.grid = grid if (grid is not None and grid.ns == ns and grid.max_count <= ops.GRID_NARROW_MAX) else None
     g.table = None
     g.strided = strided
+    g.rows_sorted = ops.rows_cutoff_pays(g.inds, conv.radius)      # searched with the deformable radius: stop at the kernel's reach
     return g
 
 

@@ -162,21 +162,30 @@ def set_search_grids(pairs):
         _grids[(inds.data_ptr(), tuple(inds.shape))] = (inds, grid)
 
 
-_sorted_rows = set()
+_sorted_rows = {}
 
 
-def set_sorted_rows(mats):
-    """index matrices whose rows are sorted by distance from the query (the output of the radius search): installed by
-    PyramidBatch.activate for the batch about to be trained on.  The linear-influence gather kernels then stop each row at the
-    reach of the kernel points (exact: the skipped influences are zeros; include/weasal_hip.h `rows_sorted`)."""
+def set_sorted_rows(pairs):
+    """[(index matrix, search radius)]: matrices whose rows are sorted by distance from the query (the output of the radius
+    search), installed by PyramidBatch.activate for the batch about to be trained on.  Where the search radius exceeds the
+    reach of a layer's kernel points (the deformable radius of datasets/common.py:500-502) the linear-influence gather kernels
+    stop each row at that reach (exact: the skipped influences are zeros; include/weasal_hip.h `rows_sorted`)."""
     _sorted_rows.clear()
-    for m in mats:
+    for m, radius in pairs:
         if isinstance(m, torch.Tensor) and m.dim() == 2 and m.shape[0] > 0:
-            _sorted_rows.add((m.data_ptr(), tuple(m.shape)))
+            _sorted_rows[(m.data_ptr(), tuple(m.shape))] = float(radius)
 
 
-def rows_are_sorted(inds):
-    return SORTED_ROW_CUTOFF and (inds.data_ptr(), tuple(inds.shape)) in _sorted_rows
+def sorted_rows_radius(inds):
+    """search radius of a registered distance-sorted matrix, None for anything else"""
+    return _sorted_rows.get((inds.data_ptr(), tuple(inds.shape))) if SORTED_ROW_CUTOFF else None
+
+
+def rows_cutoff_pays(inds, conv_radius):
+    """the rows are sorted AND were searched well beyond the convolution's own radius (kernel points lie within ~0.7 of it,
+    their influence ends `extent` = 0.4 of it further out): only then is there anything to skip"""
+    r = sorted_rows_radius(inds)
+    return r is not None and r > 1.2 * float(conv_radius)
 
 
 SORTED_ROW_CUTOFF = os.environ.get("WEASAL_ROW_CUTOFF", "1") != "0"      # A/B switch (diagnostics, tests)

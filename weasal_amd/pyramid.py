@@ -45,7 +45,8 @@ def batch_grid_subsampling(points, batches_len, sampleDl=0.1, max_p=0, random_gr
 
 
 def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_lengths,
-                        neighborhood_limits=(), random_grid_orient=True, point_orders=None, search_grids=None, rng=None):
+                        neighborhood_limits=(), random_grid_orient=True, point_orders=None, search_grids=None, rng=None,
+                        search_radii=None):
     """-> flat list  points[L] + neighbors[L] + pools[L] + upsamples[L] + lengths[L] + [features, labels]
     (datasets/common.py:574-575), all device tensors (lengths int32, indices int64).
 
@@ -64,15 +65,21 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
 
     last = {"s": None, "r": None}     # supports / radius of the previous deferred search (grid reuse)
 
+    radii_slots = []     # radius of every deferred search, in slot order
+
     def search(q, s, ql, sl, r, layer, register_order=False):
         reuse = deferred is not None and last["s"] is s and last["r"] == float(np.float32(r))
         last["s"], last["r"] = s, float(np.float32(r))
         if deferred is None:
             if not register_order:
-                return ops.radius_neighbors(q, s, ql, sl, r, dtype=torch.int64)
-            inds, order = ops.radius_neighbors(q, s, ql, sl, r, dtype=torch.int64, return_order=True)
-            orders.append((s, order))
+                inds = ops.radius_neighbors(q, s, ql, sl, r, dtype=torch.int64)
+            else:
+                inds, order = ops.radius_neighbors(q, s, ql, sl, r, dtype=torch.int64, return_order=True)
+                orders.append((s, order))
+            if search_radii is not None:
+                search_radii.append((inds, float(r)))
             return inds
+        radii_slots.append(float(r))
         if register_order:
             want_grid = search_grids is not None and q is s
             res = deferred.add(q, s, ql, sl, r, limits[layer], want_order=True, want_grid=want_grid, reuse_grid=reuse)
@@ -131,6 +138,8 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
         final = deferred.finish()
         for (lst, pos), mat in zip(slots, final):
             lst[pos] = mat
+        if search_radii is not None:
+            search_radii.extend(zip(final, radii_slots))
         for slot, grid in pending_grids:
             # the true maximum row length decides which grid backward the layer takes: the slab form up to 128 (the
             # in-degree of a support is bounded by the longest row), the queue form beyond (any in-degree); a search
@@ -169,6 +178,7 @@ class PyramidBatch:
             self.scales, self.rots, self.cloud_inds, self.center_inds, self.input_inds = input_list[5 * L + 2:5 * L + 7]
         self.point_orders = list(point_orders)   # [(points tensor, cell-order permutation)]: scheduling hints
         self.search_grids = []                   # [(index matrix, ops.SearchGrid)]: table-free backward of self-query layers
+        self.search_radii = []                   # [(index matrix, radius of the search that wrote it)]: rows sorted by distance
         self.tables = []                         # pre-built transposed tables [(inds, ns, table)] (build_tables)
         self.col0_tables = []
         self.ready = None                        # event recorded on the stream that built the batch
@@ -243,7 +253,7 @@ class PyramidBatch:
                         t.record_stream(stream)
                 self.ready = None
             ops.set_point_orders(self.point_orders)
-            ops.set_sorted_rows(self.neighbors + self.pools)      # rows as the radius search wrote them: sorted by distance
+            ops.set_sorted_rows(self.search_radii)     # rows as the radius search wrote them: sorted by distance
             ops.set_search_grids(self.search_grids)
             ops.clear_table_cache()              # tables belong to one batch
             ops.install_tables(self.tables, self.col0_tables)
@@ -252,11 +262,12 @@ class PyramidBatch:
 
 def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True,
                 with_tables=True, rng=None):
-    orders, grids = [], []
+    orders, grids, radii = [], [], []
     li = segmentation_inputs(config, points, features, labels, lengths, neighborhood_limits, random_grid_orient,
-                             point_orders=orders, search_grids=grids if points.is_cuda else None, rng=rng)
+                             point_orders=orders, search_grids=grids if points.is_cuda else None, rng=rng, search_radii=radii)
     batch = PyramidBatch(li, orders)
     batch.search_grids = grids
+    batch.search_radii = radii
     if with_tables and points.is_cuda:
         batch.build_tables()
     if points.is_cuda:
