@@ -390,12 +390,19 @@ def main():
                     traffic = tj.get("kpconv_gather_fwd_bytes_per_launch", {}).get("%s:%d:%d" % (args.workload, h, ci))
                 except Exception:
                     traffic = None
-            nt = 1 if ci <= 16 else (2 if ci <= 32 else (4 if ci <= 64 else (8 if ci <= 128 else 16)))
             deform = "deform" in args.workload
+            # the kernel the library's dispatcher launches for this layer (ws_kpconv_gather_fwd_variant: the same selection
+            # rules as the launch).  In the deformable workloads the timed launch is the rigid OFFSET convolution of the
+            # first deformable block; rows searched with the deformable radius take the sorted-row cutoff.
+            import ctypes as _C
+            from weasal_amd import _lib as _wl
+            name = _C.create_string_buffer(256)
+            _wl.check(_wl.lib().ws_kpconv_gather_fwd_variant(ci, 0, 0, 0, 1 if bf16 else 0, 1 if deform else 0, name, 256))
             res["roofline"] = {"bound": "hbm",
-                               "kernel": "kpconv_gather_fwd_mfma_kernel<%d,%d,false,true,%s> (the rigid gather of the largest layer: "
-                                         "N=%d queries, H=%d, Ci=%d)" % (nt, 0, "bf16" if bf16 else "float", nq, h, ci)
-                                         + ("; this workload's deformable gathers run the <.,1,true,...> instantiation" if deform else ""),
+                               "kernel": name.value.decode() + " on N=%d queries, H=%d, Ci=%d" % (nq, h, ci)
+                                         + ("; rows from the deformable search radius: the kernel walks each (distance-sorted) row only "
+                                            "up to the reach of the kernel points, B_fwd still counts every one of the H neighbours the "
+                                            "reference gathers" if deform else ""),
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "achieved_is": "SURVEY 8d logical-gather bytes B_fwd / launch time (every neighbour reference "

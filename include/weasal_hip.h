@@ -589,6 +589,10 @@ int ws_kpconv_gather_bwd_geom_def(const float* q_pts, int64_t nq, const float* s
                                   const void* x, int32_t ci, const void* dwf, const float* kp4, int32_t k, const float* d_min_d2,
                                   float extent, const int32_t* order, float* d_kp4, int32_t rows_bf16, int32_t rows_sorted,
                                   void* stream);
+/* name of the forward gather kernel the library launches for a layer of ci channels (mode 0 rigid, 1 deformable through the
+ * generic entries, 2 deformable fast path): for reports, no device work */
+int ws_kpconv_gather_fwd_variant(int32_t ci, int32_t mode, int32_t influence, int32_t aggregation, int32_t rows_bf16,
+                                 int32_t rows_sorted, char* out, int32_t cap);
 int64_t ws_p2p_regularizer_scratch_bytes(int64_t n);
 int ws_p2p_regularizer_fwd(const float* deformed_kp, const float* kp4, const float* min_d2, int64_t n, int32_t k, float extent,
                            float repulse_extent, float* out2, void* scratch, void* stream);

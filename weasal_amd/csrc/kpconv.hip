@@ -2501,6 +2501,32 @@ int ws_kpconv_gather_bwd_geom_def(const float* q_pts, int64_t nq, const float* s
                                            order, dk, stream, rows_sorted);
 }
 
+// Name of the forward gather kernel the dispatchers above launch for a layer (bench.py's roofline.kernel): same selection
+// rules as gather_fwd_impl / gather_fwd_def_impl for 16-byte aligned rows.  mode: 0 rigid (kernel_points), 1 deformable
+// through the generic entries, 2 deformable fast path (kp4).
+int ws_kpconv_gather_fwd_variant(int32_t ci, int32_t mode, int32_t influence, int32_t aggregation, int32_t rows_bf16,
+                                 int32_t rows_sorted, char* out, int32_t cap)
+{
+    WS_REQUIRE(out && cap > 0 && ci >= 1, "bad argument");
+    const char* t = rows_bf16 ? "bf16" : "float";
+    const bool fast = influence == WS_INFLUENCE_LINEAR && aggregation == WS_AGGREGATION_SUM;
+    if (mode == 2 || (ws_kpconv_variant == 2 && ci > 4)) {
+        int nt = ci <= 16 ? 1 : (ci <= 32 ? 2 : (ci <= 64 ? 4 : (ci <= 128 ? 8 : 16)));
+        if (ci % nt) nt = 1;
+        const int m = mode == 2 ? 2 : (mode == 1 ? 1 : (fast ? 0 : 1));
+        const bool cut = rows_sorted && (m == 2 || m == 0);
+        snprintf(out, (size_t)cap, "kpconv_gather_fwd_mfma_kernel<NT=%d, MODE=%d, DEF=%s, VECROW=true, %s, GS=default, CUT=%s>", nt, m,
+                 mode ? "true" : "false", t, cut ? "true" : "false");
+        return WS_OK;
+    }
+    const int vec4 = ci % 4 == 0;
+    const int g = (ci <= 4) ? (vec4 ? 1 : 4) : (ci <= 8 ? 2 : (ci <= 16 ? 4 : (ci <= 32 ? 8 : 16)));
+    snprintf(out, (size_t)cap, "kpconv_gather_fwd_kernel<K=15, G=%d, MODE=%d, DEF=%s, VEC=%s, PW=%d, %s>%s", g, (mode || !fast) ? 1 : 0,
+             mode ? "true" : "false", vec4 ? "true" : "false", (ci <= 4 && !vec4) ? 1 : 4, t,
+             (rows_sorted && !mode && fast) ? " (sorted-row cutoff on)" : "");
+    return WS_OK;
+}
+
 int ws_kpconv_gather_fwd(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns,
                          const int64_t* inds, int32_t h, const float* x, int32_t ci,
                          const float* kernel_points, int32_t k, const float* deformed_kp,

@@ -377,7 +377,7 @@ class _KPConvGatherDef(torch.autograd.Function):
         bf = x.dtype == torch.bfloat16
         wf = torch.empty((nq, k, ci), dtype=x.dtype, device=x.device)
         min_d2 = torch.empty((nq, k), dtype=torch.float32, device=x.device)
-        tok = _tbegin("kpconv_gather_fwd", nq, h, ci)
+        tok = _tbegin("kpconv_gather_fwd_def", nq, h, ci)
         check(lib.ws_kpconv_gather_fwd_def(ptr(q_pts), nq, ptr(s_pts), ns, ptr(inds), h, ptr(x), ci, ptr(kp4), k, float(extent),
                                            ptr(_order_for(q_pts)), ptr(wf), ptr(min_d2), 1 if bf else 0, 1 if rows_sorted else 0,
                                            current_stream()))
