@@ -202,9 +202,9 @@ def main():
     ap.add_argument("--dp-buckets", type=int, default=int(os.environ.get("WEASAL_DP_BUCKETS", "1")),
                     help="N > 1 only: >1 cuts the gradient buffer into that many ranges whose all-reduce is launched "
                          "from gradient hooks during backward (opt-in; 1 = one all-reduce after backward)")
-    ap.add_argument("--contrast", type=int, default=0,
-                    help="1: add KPFCNN.contrast_loss to the step (trainer_PseudoLabel.py:204-208; SURVEY 8f-2, "
-                         "outside the north_star step, so off by default)")
+    ap.add_argument("--contrast", type=int, default=1,
+                    help="1 (default): the step includes KPFCNN.contrast_loss, as the reference's pseudo-label step does from "
+                         "epoch 0 (trainer_PseudoLabel.py:204-208, contrast_start = 0); 0: cross entropy (+ regulariser) only")
     ap.add_argument("--blas", default="", help="torch.backends.cuda.preferred_blas_library (A/B only)")
     ap.add_argument("--prefetch", type=int, default=1,
                     help="1: build the pyramid of the next batches on a second HIP stream / host thread while the "
@@ -352,7 +352,7 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
                "config": {"workload": wl["name"] + (", bf16 feature rows / fp32 accumulate / fp32 geometry" if bf16 else ", fp32")
                           + ", step = GPU pyramid + fwd + loss + bwd" + exch + " + SGD"
-                          + ("; contrast_loss term included" if args.contrast else "; contrast_loss term (trainer_PseudoLabel.py:204-208) not in this step, see --contrast 1")
+                          + ("; contrast_loss term included (trainer_PseudoLabel.py:204-208)" if args.contrast else "; contrast_loss term (trainer_PseudoLabel.py:204-208) left out (--contrast 0)")
                           + ("; pyramid of the next batch overlapped on a second stream" if args.prefetch else ""),
                           "points_per_step_per_gpu": n_points, "parallelism": "dp%d" % world,
                           "dist_backend": backend,

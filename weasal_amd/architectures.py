@@ -232,20 +232,25 @@ class KPFCNN(nn.Module):
         certain_label = (pseudo_logits > threshold) | label_id
         pseudo_lbs = torch.argmax(prob, dim=1)
         pseudo_lbs = torch.where(label_id, labels.to(pseudo_lbs.dtype), pseudo_lbs)
-        all_valid_idx = torch.where(certain_label)[0]
-        num_valid = all_valid_idx.shape[0]
-        if num_valid < 1:
-            print('Skipped loss calculations because there are no valid points in batch')
-            return torch.zeros((), dtype=torch.float32, device=dev)
-        n_draw = slc_con if num_valid >= slc_con else slc_con - num_valid
+        # ---- the slice of slc_con valid points (:437-454) WITHOUT host synchronisation.  The reference lists the valid points
+        # (torch.where: the host must learn their number) and draws torch.randint(0, num_valid) positions in that list.  Here
+        # the r-th valid point is found on the device: cs = running count of valid points, position r <-> the first i with
+        # cs[i] = r + 1 (a binary search per draw); num_valid = cs[-1] stays a device scalar and the draws are
+        # floor(u * num_valid) of slc_con device uniforms -- the same distribution as randint.  The branch for fewer than slc_con
+        # valid points (:450-454: all of them once, then random repeats) is the same fixed-size expression.
+        cs = torch.cumsum(certain_label.to(torch.int64), dim=0)
+        num_valid = cs[-1]                                           # device scalar
+        j = torch.arange(slc_con, device=dev)
         if slice_draw is None:
-            slice_draw = torch.randint(0, num_valid, (n_draw,))
-        slice_draw = slice_draw.to(dev)
-        if num_valid >= slc_con:
-            slc_idx_idx = slice_draw
-        else:
-            slc_idx_idx = torch.cat((torch.arange(num_valid, device=dev), slice_draw), dim=0)
-        slc_idx = all_valid_idx[slc_idx_idx]
+            u = torch.rand(slc_con, device=dev)
+            r_rand = (u * num_valid.to(torch.float32)).floor().to(torch.int64)
+            r = torch.where((num_valid < slc_con) & (j < num_valid), j, r_rand)
+        else:                                                        # explicit draw (tests): its length tells the branch
+            slice_draw = slice_draw.to(dev).to(torch.int64)
+            nv_host = slc_con - slice_draw.shape[0]
+            r = slice_draw if nv_host <= 0 else torch.cat((torch.arange(nv_host, device=dev), slice_draw), dim=0)
+        r = torch.minimum(r, (num_valid - 1).clamp(min=0).to(torch.int64))
+        slc_idx = torch.searchsorted(cs, r + 1).clamp(max=N - 1)
 
         # [N, slc_con] part (:455-497): masks, temperature-scaled similarities, masked log-softmax and the mean
         # over the positives -- one fused HIP kernel per direction, nothing of size [N, slc_con] is stored
@@ -263,7 +268,9 @@ class KPFCNN(nn.Module):
         per_class = sums / cnts.clamp(min=1)
         sel = (per_class > 0).to(pts_loss.dtype)
         self.pts_loss = per_class
-        return (per_class * sel).sum() / sel.sum()
+        loss = (per_class * sel).sum() / sel.sum()
+        # no valid point at all: the reference returns 0 before any of the above (:441-443)
+        return torch.where(num_valid > 0, loss, torch.zeros((), dtype=loss.dtype, device=dev))
 
     def accuracy(self, outputs, labels):
         target = self._targets(labels)
