@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen", "dales_deform", "dales_deform_f32"])
+    ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen", "dales_deform", "dales_deform_f32", "vaihingen_wl"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--dp-buckets", type=int, default=int(os.environ.get("WEASAL_DP_BUCKETS", "1")),
@@ -233,7 +233,13 @@ def main():
     cfg = cfg_cls()
     np.random.seed(1234 + rank)
     torch.manual_seed(1234)            # same initial replica everywhere
-    net = KPFCNN(cfg, np.arange(9), []).to(dev)
+    weak = getattr(cfg, "model_name", "") == "KPFCNN_mprm"          # BASELINE config 1: the weak-label step
+    if weak:
+        from weasal_amd.architectures import KPFCNN_mprm
+        from weasal_amd.trainer import train_step_weak
+        net = KPFCNN_mprm(cfg, np.arange(cfg.num_classes), []).to(dev)
+    else:
+        net = KPFCNN(cfg, np.arange(9), []).to(dev)
     net.train()
     dp.broadcast_parameters(net)
     opt = make_optimizer(net, cfg)
@@ -243,12 +249,16 @@ def main():
 
     # inputs resident in HBM before the timed region (seed = 1000*rank + step)
     nd = max(1, min(args.distinct_batches, args.steps + args.warmup))
-    inputs = []
+    inputs, weak_labels = [], []
     for i in range(nd):
         pts, feats, labels, lens = synthetic.make_inputs(1000 * rank + i, wl["spheres"], wl["points"], wl["radius"],
                                                          cfg.in_features_dim)
         inputs.append((torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev),
                        torch.from_numpy(labels).to(dev), lens))
+        if weak:
+            region, region_lb, cloud_lb, centers = synthetic.make_weak_labels(1000 * rank + i, pts, labels, lens,
+                                                                              num_classes=cfg.num_classes)
+            weak_labels.append((region, region_lb, torch.from_numpy(cloud_lb).to(dev), torch.from_numpy(centers).to(dev)))
     n_points = int(inputs[0][3].sum())
 
     timer = KernelTimer()
@@ -271,15 +281,23 @@ def main():
 
     waits = {"prefetch": 0.0, "limiter": 0.0}
 
+    served = [0]
+
     def step(i):
         if prefetcher is not None:
             tw0 = time.perf_counter()
             batch = next(prefetcher)              # blocks while the side stream is still building this batch
             waits["prefetch"] += time.perf_counter() - tw0
+            i = served[0]                         # the prefetcher hands the inputs out in source order
+            served[0] += 1
         else:
             pts, feats, labels, lens = inputs[i % nd]
             batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
-        loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync, epoch=0 if args.contrast else None)
+        if weak:
+            batch.region, batch.region_lb, batch.cloud_lb, batch.center_pts = weak_labels[i % nd]
+            loss, _ = train_step_weak(net, opt, batch, cfg, grad_sync=sync)
+        else:
+            loss, _ = train_step(net, opt, batch, cfg, grad_sync=sync, epoch=0 if args.contrast else None)
         tw0 = time.perf_counter()
         limiter.tick(batch)          # bounds the host's run-ahead (4 steps); checks the K4G capacity flags off the hot path
         waits["limiter"] += time.perf_counter() - tw0

@@ -167,3 +167,44 @@ class DALESDeformF32Config(DALESDeformConfig):
     """the same network with f32 rows (A/B of the bf16 path; oracle comparisons at 1e-4)"""
     dataset = 'DALESDeformF32'
     feature_dtype = 'f32'
+
+
+_WL_ARCH = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb',
+            'nearest_upsample', 'nearest_upsample']
+
+
+class Vaihingen3DWLConfig(Config):
+    """values of train_Vaihingen3D_WeakLabel.py:46-178 that reach the weak-label step (BASELINE config 1): the 3-layer
+    multi-path region-mining network KPFCNN_mprm, 64 first features, dl0 0.24, the region loss, gradient-NORM clipping at 1"""
+    dataset = 'Vaihingen3DWL'
+    input_threads = 10
+    architecture = list(_WL_ARCH)
+    num_kernel_points = 15
+    in_radius = 18
+    sub_radius = 5
+    first_subsampling_dl = 0.24
+    conv_radius = 2.5
+    deform_radius = 1.0
+    KP_extent = 1.0
+    KP_influence = 'linear'
+    aggregation_mode = 'sum'
+    first_features_dim = 64
+    in_features_dim = 4
+    modulated = False
+    use_batch_norm = True
+    batch_norm_momentum = 0.02
+    deform_fitting_mode = 'point2point'
+    deform_fitting_power = 1.0
+    deform_lr_factor = 0.1
+    repulse_extent = 1.2
+    max_epoch = 80
+    learning_rate = 0.01
+    momentum = 0.98
+    lr_decays = {i: 0.98 for i in range(1, 1000)}
+    grad_clip_norm = 1
+    batch_num = 3
+    class_w = [1, 1, 1, 1, 1, 1, 1, 1, 1]
+    num_classes = 9
+    model_name = 'KPFCNN_mprm'
+    loss_type = 'region_mprm_loss'
+    anchor_method = 'reduced'

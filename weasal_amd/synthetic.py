@@ -19,6 +19,9 @@ WORKLOADS = {
                                   "in_radius=10m, 50k pts/sphere, batch=8"),
     "vaihingen": dict(config="Vaihingen3DPLConfig", radius=4.0, points=3000, spheres=4, limits=[],
                       name="Vaihingen3D_PseudoLabel KP-FCNN, in_radius=4m, 3k pts/sphere, batch=4"),
+    # BASELINE config 1: the weak-label step of KPFCNN_mprm, 2 spheres of 3 000 points, R = 4 m
+    "vaihingen_wl": dict(config="Vaihingen3DWLConfig", radius=4.0, points=3000, spheres=2, limits=[],
+                         name="Vaihingen3D_WeakLabel KPFCNN_mprm, in_radius=4m, 3k pts/sphere, batch=2"),
 }
 
 
@@ -45,3 +48,31 @@ def make_inputs(seed, spheres, points, radius, in_features_dim, num_classes=9):
     labels = rng.integers(0, num_classes, size=n).astype(np.int64)
     lens = np.full(spheres, points, np.int32)
     return pts, feats.astype(np.float32), labels, lens
+
+
+def make_weak_labels(seed, points, labels, lens, sub_radius=1.5, anchors_per_sphere=3, num_classes=9):
+    """Synthetic weak (region) labels in the layout of the reference's weak-label batches (datasets/Vaihingen3D_WeakLabel.py:
+    414-447, 503-525): per input sphere a list of sub-regions -- index arrays LOCAL to the sphere, each with a multi-hot
+    label vector of the classes present in it -- the per-sphere multi-hot cloud label and the sphere centres.
+    -> (region [B][r] int64 arrays, region_lb [B][r] float32 [C], cloud_lb float32 [B, C], center_pts float32 [B, 3])"""
+    rng = np.random.default_rng(seed)
+    region, region_lb, cloud_lb, centers = [], [], [], []
+    i0 = 0
+    for n in lens:
+        n = int(n)
+        p = points[i0:i0 + n]
+        lab = labels[i0:i0 + n]
+        regs, lbs = [], []
+        for _ in range(anchors_per_sphere):
+            a = p[rng.integers(0, n)]
+            idx = np.nonzero(((p - a) ** 2).sum(1) < sub_radius ** 2)[0].astype(np.int64)
+            if idx.size == 0:
+                continue
+            regs.append(idx)
+            lbs.append(np.bincount(lab[idx], minlength=num_classes)[:num_classes].astype(bool).astype(np.float32))
+        region.append(regs)
+        region_lb.append(lbs)
+        cloud_lb.append(np.bincount(lab, minlength=num_classes)[:num_classes].astype(bool).astype(np.float32))
+        centers.append(np.append(p[:, :2].mean(0), rng.uniform(250.0, 300.0)).astype(np.float32))      # absolute height of the sphere centre
+        i0 += n
+    return region, region_lb, np.stack(cloud_lb), np.stack(centers)

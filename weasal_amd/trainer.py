@@ -106,6 +106,40 @@ def train_step(net, optimizer, batch, config, grad_sync=None, epoch=None):
     return loss, outputs
 
 
+def train_step_weak(net, optimizer, batch, config, grad_sync=None):
+    """One step of the WEAK-LABEL trainer (utils/trainer_WeakLabel.py:181-216) for KPFCNN_mprm:
+      skip batches without sub-region labels (:181-184) -> zero_grad -> logits, class_logits, cam = net(batch, config) ->
+      region_mprm_loss(cam, batch.region, batch.region_lb, batch.lengths[0]) or class_logits_loss(class_logits,
+      batch.cloud_lb) by config.loss_type (:203-207) -> backward -> [all-reduce] -> clip_grad_NORM_(grad_clip_norm) (:216;
+      the pseudo-label trainer clips by value) -> SGD step.
+    -> (loss, (logits, class_logits, cam)), or (None, None) for a skipped batch."""
+    if not any(len(r) > 0 for r in batch.region):
+        return None, None
+    optimizer.zero_grad(set_to_none=grad_sync is None)
+    logits, class_logits, cam = net(batch, config)
+    if config.loss_type == 'region_mprm_loss':
+        loss = net.region_mprm_loss(cam, batch.region, batch.region_lb, batch.lengths[0])
+    else:
+        loss = net.class_logits_loss(class_logits, batch.cloud_lb)
+    if grad_sync is not None and hasattr(grad_sync, "arm"):
+        grad_sync.arm()
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync(net)
+    if config.grad_clip_norm > 0:
+        params = getattr(net, "_param_list", None)
+        if params is None:
+            params = [p for p in net.parameters()]
+            net._param_list = params
+        # total norm, coefficient and scaling stay on the device (no synchronisation); the value is kept for the log line
+        net.grad_norm = torch.nn.utils.clip_grad_norm_(params, config.grad_clip_norm)
+    if isinstance(optimizer, FusedSGD):
+        optimizer.step(clip_value=0.0)
+    else:
+        optimizer.step()
+    return loss, (logits, class_logits, cam)
+
+
 def freeze_gc():
     """Call once after the model, optimizer and the first batches exist: moves everything alive into the
     garbage collector's permanent generation.  Without it CPython's full (generation-2) collection walks the
