@@ -35,7 +35,10 @@ def _rel(a, b):
 
 
 @pytest.mark.timeout(3000)
-def test_every_encoder_block_at_dales_width_vs_oracle(gpu):
+@pytest.mark.parametrize("use_bn", [True, False])
+def test_every_encoder_block_at_dales_width_vs_oracle(gpu, use_bn):
+    """use_bn False: BatchNormBlock is a learned bias (blocks.py:465) -- b1 / bk / b2 and the shortcut's bias and their
+    gradients are live (random values), none of the block call's bias-free shortcuts (gated epilogues) applies"""
     from oracle import kpconv_ref
     from test_fullwidth_gpu import _cpu_copy
     from weasal_amd import config as wcfg, pyramid, synthetic
@@ -43,9 +46,16 @@ def test_every_encoder_block_at_dales_width_vs_oracle(gpu):
     wl = synthetic.WORKLOADS["dales"]
     cfg = wcfg.DALESPLConfig()
     cfg.dropout = 0.0
+    cfg.use_batch_norm = use_bn
     np.random.seed(3)
     torch.manual_seed(3)
     net = KPFCNN(cfg, np.arange(9), [])
+    if not use_bn:
+        gen0 = torch.Generator().manual_seed(17)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if name.endswith(".bias"):
+                    p.copy_(0.1 * torch.randn(p.shape, generator=gen0))
     net_cpu = copy.deepcopy(net)
     net.to(gpu).train()
     net_cpu.train()
@@ -93,15 +103,27 @@ def test_every_encoder_block_at_dales_width_vs_oracle(gpu):
         # ---- the GPU's own LeakyReLU decisions, from the operator-by-operator run of the same kernels
         acts_g = {}
         hk = hooked(blk, acts_g)
+        grads_call = {n_: p.grad.clone() for n_, p in blk.named_parameters() if p.grad is not None}
         fused.FUSED_BLOCKS = False
         try:
-            with torch.no_grad():
-                out_ops = blk(inputs[i].to(gpu), batch)
+            x_o = inputs[i].to(gpu).requires_grad_(True)
+            blk.zero_grad()
+            out_ops = blk(x_o, batch)
+            out_ops.backward(dy.to(gpu))
         finally:
             fused.FUSED_BLOCKS = True
         for h_ in hk:
             h_.remove()
+        # the block call against the operator-by-operator path: the same kernels in the same order -- every output and
+        # EVERY parameter gradient (the shortcut's bias included) to fp32 re-association of one accumulation
         assert _rel(out_ops, out_g) < 1e-6
+        if i > 0:
+            assert _rel(x_g.grad, x_o.grad) < 2e-6, i
+        for n_, p in blk.named_parameters():
+            assert (p.grad is None) == (n_ not in grads_call), n_
+            if p.grad is not None:
+                assert _rel(grads_call[n_], p.grad) < 2e-6, (i, n_)
+                p.grad = grads_call[n_]
         strided = "strided" in blk.block_name
         lvl = blk.layer_ind
         inds = (batch_cpu.pools[lvl] if strided else batch_cpu.neighbors[lvl])
@@ -140,7 +162,7 @@ def test_every_encoder_block_at_dales_width_vs_oracle(gpu):
             entry["d_" + name] = _rel(p.grad, ref_p[name].grad)
         report["encoder_blocks.%d" % i] = entry
     os.makedirs(os.path.dirname(REPORT), exist_ok=True)
-    json.dump(report, open(REPORT, "w"), indent=1, sort_keys=True)
+    json.dump(report, open(REPORT.replace(".json", "_bn.json" if use_bn else "_bias.json"), "w"), indent=1, sort_keys=True)
     clean = 0
     for key, entry in report.items():
         nflip = sum(entry["flips"].values())

@@ -70,3 +70,24 @@ def test_projection_votes_confusion_potentials_on_the_gpu(gpu):
     mn, am = tester.update_potentials(dev(g["pot_points"]), pots, g["center"], float(g["in_radius"]))
     assert np.abs(pots.cpu().numpy() - g["pots1"]).max() <= 4e-16
     assert int(am.item()) == int(g["argmin1"]) and float(mn.item()) == float(pots.cpu().numpy().min())
+
+
+@pytest.mark.gpu
+def test_ignored_labels_and_unvisited_points(gpu):
+    """tests/golden/g13_tester_ignored.npz (the reference tester's zero-column insertion and row / column deletion,
+    tester_PseudoLabel.py:228-250, 287-307): an ignored label in front of the valid ones (DALES: 0 = unclassified), or in the
+    middle; sub-cloud points no sphere ever voted on"""
+    from weasal_amd import tester
+    g, s = golden("g11_tester.npz"), golden("g13_tester_ignored.npz")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    votes = tester.VoteAccumulator([g["sub"].shape[0]], 9, gpu, test_smooth=0.95)
+    votes.probs[0].copy_(dev(g["test_probs"]))
+    assert int((g["test_probs"].sum(1) == 0).sum()) > 0
+    for tag in ("first", "middle"):
+        lv, ign = s[tag + "/label_values"], s[tag + "/ignored"]
+        for name, proj in (("sub", None), ("full", dev(g["proj"]))):
+            preds, conf = votes.predictions(0, proj=proj, labels=dev(s["%s/%s/targets" % (tag, name)]), label_values=lv,
+                                            ignored_labels=ign)
+            assert np.array_equal(preds.cpu().numpy(), s["%s/%s/preds" % (tag, name)]), (tag, name)
+            assert np.array_equal(conf.cpu().numpy(), s["%s/%s/conf" % (tag, name)]), (tag, name)
+            assert np.array_equal(tester.IoU_from_confusions(conf.cpu().numpy()), s["%s/%s/iou" % (tag, name)])

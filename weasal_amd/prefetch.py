@@ -43,7 +43,8 @@ class PyramidPrefetcher:
     with the training thread waiting 0.2-0.3 ms per step for the next batch (14.34-14.45 vs 14.38-14.51 ms with two).
     Two builders (the default, WEASAL_PREFETCH_WORKERS) overlap their chains and keep a margin.  With `seed` each worker draws the grid orientations from its own RandomState(seed + worker);
     without, the draws come from the global np.random in source order (taken under the source lock when a batch is handed to a
-    worker), i.e. the reference's stream exactly, whatever the number of workers."""
+    worker): one process-wide stream consumed in batch order whatever the number of workers (the reference draws inside its
+    forked DataLoader workers, each with its own copy of the state: there is no single reference stream to match)."""
 
     def __init__(self, config, source, neighborhood_limits=(), depth=2, random_grid_orient=True, device=None, seed=None,
                  workers=None):
@@ -75,6 +76,14 @@ class PyramidPrefetcher:
         for t in self.threads:
             t.start()
 
+    def _encoder_len(self):
+        """blocks up to the first upsampling / global block: where the pyramid schedule stops (datasets/common.py:566-568)"""
+        arch = self.config.architecture
+        for i, b in enumerate(arch):
+            if 'global' in b or 'upsample' in b:
+                return i + 1
+        return len(arch)
+
     def _take(self):
         """-> (sequence number, item) or None when the source is exhausted; waits while the pipeline is `depth` ahead"""
         with self._cv:
@@ -97,7 +106,10 @@ class PyramidPrefetcher:
                 # under the source lock, and replayed by the worker
                 import numpy as np
                 nb = len(item[3])
-                rng = _Replay(np.random.rand(3 * nb * max(self.config.num_layers - 1, 0)))
+                # one (theta, phi, alpha) triple per sphere for every block that subsamples (pyramid.segmentation_inputs
+                # calls batch_grid_subsampling exactly there), counted from the architecture itself
+                pools = sum(1 for b in self.config.architecture[:self._encoder_len()] if 'pool' in b or 'strided' in b)
+                rng = _Replay(np.random.rand(3 * nb * pools))
             return seq, item, rng
 
     def _run(self, w):

@@ -149,26 +149,45 @@ class VoteAccumulator:
                                      ptr(inds[i0:i0 + n]), ptr(p), p.shape[0], self.smooth, current_stream()))
             i0 += n
 
-    def predictions(self, cloud, proj=None, labels=None, label_values=None):
+    def predictions(self, cloud, proj=None, labels=None, label_values=None, ignored_labels=()):
         """-> (preds int32 [M] as label VALUES, confusion int64 [C, C] or None): arg-max of the (re-projected) votes and
-        the confusion against `labels` (label values; mapped to positions in the sorted label_values like fast_confusion)"""
+        the confusion against `labels` (label values; mapped to positions in the sorted label_values like fast_confusion).
+
+        `ignored_labels` (tester_PseudoLabel.py:228-250, 287-307): `label_values` then names ALL labels of the dataset, the
+        votes have one column per label that is not ignored.  The reference inserts a zero column per ignored label before
+        the arg-max -- which only matters for a point without any vote (all zeros: outside every sphere's 0.7-radius mask):
+        it arg-maxes to the FIRST label, ignored or not -- and deletes the ignored rows and columns from the confusion, so a
+        point whose target or prediction is an ignored label is not counted.  Both are reproduced: such a point is
+        predicted as label_values[0], and leaves the confusion when that label is ignored."""
         lib = _lib.lib()
         p = self.probs[cloud]
         dev = p.device
         m = p.shape[0] if proj is None else proj.shape[0]
-        lv = np.sort(np.asarray(label_values if label_values is not None else np.arange(self.c))).astype(np.int64)
+        lv_all = np.sort(np.asarray(label_values if label_values is not None else np.arange(self.c))).astype(np.int64)
+        ign = np.asarray(sorted(ignored_labels), np.int64)
+        lv = np.array([v for v in lv_all if v not in ign], np.int64)                 # the labels the vote columns stand for
         if len(lv) != self.c:
-            raise ValueError("label_values must name the %d classes of the votes" % self.c)
+            raise ValueError("label_values minus ignored_labels must name the %d classes of the votes" % self.c)
         pj = None if proj is None else proj.detach().to(torch.int32).contiguous()
         preds = torch.empty(m, dtype=torch.int32, device=dev)
+        first_ignored = len(ign) > 0 and lv_all[0] in ign
+        voted = None
+        if len(ign) > 0:
+            rows = p if pj is None else p[pj.long()]
+            voted = rows.amax(dim=1) > 0                                            # (votes are probabilities: >= 0)
         conf = lab = None
         if labels is not None:
-            lut = torch.full((int(max(lv.max(), int(labels.max())) + 2),), -1, dtype=torch.int32, device=dev)
+            lut = torch.full((int(max(lv_all.max(), int(labels.max())) + 2),), -1, dtype=torch.int32, device=dev)
             lut[torch.from_numpy(lv).to(dev)] = torch.arange(self.c, dtype=torch.int32, device=dev)
-            lab = lut[labels.detach().to(torch.int64).clamp_min(0)].contiguous()
+            lab = lut[labels.detach().to(torch.int64).clamp_min(0)]
+            if first_ignored:
+                lab = torch.where(voted, lab, torch.full_like(lab, -1))            # predicted as an ignored label: not counted
+            lab = lab.contiguous()
             conf = torch.zeros((self.c, self.c), dtype=torch.int64, device=dev)
         check(lib.ws_project_confusion(ptr(p), self.c, ptr(pj), m, ptr(lab), ptr(preds), self.c, ptr(conf), current_stream()))
         values = torch.from_numpy(lv.astype(np.int32)).to(dev)[preds.long()]
+        if voted is not None:
+            values = torch.where(voted, values, torch.full_like(values, int(lv_all[0])))
         return values, conf
 
 

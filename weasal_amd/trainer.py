@@ -168,9 +168,11 @@ class InFlightLimiter:
         self._ticks = 0
 
     def tick(self, batch=None):
-        """batch: the PyramidBatch this step trained on.  Its table-free backward launches (K4G) write a capacity flag
-        (`SearchGrid.overflow`, set if a support ever had more incoming pairs than the slab holds -- impossible while the
-        search reported rows <= 128, so a set flag means a stale or mutated grid).  The flags are folded into a running
+        """batch: the PyramidBatch this step trained on.  Its table-free backward launches (K4G, slab form) write a capacity
+        flag (`SearchGrid.overflow`, set if a support ever had more incoming pairs than the slab holds).  The host already
+        refuses the slab form for a grid whose search recorded rows longer than 128 (`SearchGrid.max_count`: such layers
+        take the queue form or the transposed table), so a set flag means a stale or mutated grid: a pure assertion.
+        Callers that want it checked pass `batch` here and call finish() after the last step.  The flags are folded into a running
         maximum on the device (two tiny launches); every `check_every`-th step that maximum travels to the host with an
         asynchronous copy and is checked `depth` steps later, when its event has completed anyway: never silent, never a
         synchronisation on the step.  (A device-to-host copy EVERY step cost 0.25 ms of idle training stream per step:
@@ -200,10 +202,13 @@ class InFlightLimiter:
             self._check(fl)
 
     def _land(self, dev):
+        n = int(dev.shape[0])
         if len(self._pinned) <= self.depth + 1:              # a small ring of pinned landing buffers, allocated once
-            self._pinned.append(torch.zeros(64, dtype=dev.dtype, pin_memory=True))
+            self._pinned.append(torch.zeros(max(64, n), dtype=dev.dtype, pin_memory=True))
         self._slot = (self._slot + 1) % len(self._pinned)
-        flags = self._pinned[self._slot][:dev.shape[0]]
+        if self._pinned[self._slot].shape[0] < n:            # more grids than the buffer was sized for: a larger one
+            self._pinned[self._slot] = torch.zeros(n, dtype=dev.dtype, pin_memory=True)
+        flags = self._pinned[self._slot][:n]
         flags.copy_(dev, non_blocking=True)
         return flags
 
