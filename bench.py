@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--contrast", type=int, default=1,
                     help="1 (default): the step includes KPFCNN.contrast_loss, as the reference's pseudo-label step does from "
                          "epoch 0 (trainer_PseudoLabel.py:204-208, contrast_start = 0); 0: cross entropy (+ regulariser) only")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="infer: a step = GPU pyramid + forward only under no_grad (the testers' voting passes, "
+                         "utils/tester_PseudoLabel.py:164); the level-0 32 -> 32 KPConv layers then run as one launch each")
     ap.add_argument("--blas", default="", help="torch.backends.cuda.preferred_blas_library (A/B only)")
     ap.add_argument("--prefetch", type=int, default=1,
                     help="1: build the pyramid of the next batches on a second HIP stream / host thread while the "
@@ -240,7 +243,7 @@ def main():
         net = KPFCNN_mprm(cfg, np.arange(cfg.num_classes), []).to(dev)
     else:
         net = KPFCNN(cfg, np.arange(9), []).to(dev)
-    net.train()
+    net.train() if args.mode == "train" else net.eval()
     dp.broadcast_parameters(net)
     opt = make_optimizer(net, cfg)
     sync = dp.GradSync(buckets=args.dp_buckets) if world > 1 else None
@@ -293,7 +296,11 @@ def main():
         else:
             pts, feats, labels, lens = inputs[i % nd]
             batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
-        if weak:
+        if args.mode == "infer":
+            with torch.no_grad():
+                out = net(batch, cfg)
+            loss = out[0].sum() if isinstance(out, tuple) else out.sum()      # (something to read back at the end)
+        elif weak:
             batch.region, batch.region_lb, batch.cloud_lb, batch.center_pts = weak_labels[i % nd]
             loss, _ = train_step_weak(net, opt, batch, cfg, grad_sync=sync)
         else:
@@ -357,7 +364,8 @@ def main():
         es = 2 if bf16 else 4
         backend = dist.get_backend() if world > 1 else None
         exch = "" if world == 1 else (" + RCCL grad all-reduce" if backend == "nccl" else " + %s grad all-reduce (NOT RCCL: rehearsal backend)" % backend)
-        res = {"metric": "points/sec fwd+bwd KPFCNN on DALES spheres; achieved HBM GB/s on KPConv gather",
+        res = {"metric": "points/sec fwd+bwd KPFCNN on DALES spheres; achieved HBM GB/s on KPConv gather" if args.mode == "train" else
+                         "points/sec forward-only (inference pass) KPFCNN on DALES spheres; achieved HBM GB/s on the KPConv layer",
                "value": world * n_points * args.steps / dt, "unit": "points/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                # host side of the training thread: wall time to issue the K steps, and the same without the time it spent
@@ -369,7 +377,8 @@ def main():
                "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
                "config": {"workload": wl["name"] + (", bf16 feature rows / fp32 accumulate / fp32 geometry" if bf16 else ", fp32")
-                          + ", step = GPU pyramid + fwd + loss + bwd" + exch + " + SGD"
+                          + (", step = GPU pyramid + fwd + loss + bwd" + exch + " + SGD" if args.mode == "train" else
+                             ", step = GPU pyramid + forward under no_grad (the voting test's pass)")
                           + ("; contrast_loss term included (trainer_PseudoLabel.py:204-208)" if args.contrast else "; contrast_loss term (trainer_PseudoLabel.py:204-208) left out (--contrast 0)")
                           + ("; pyramid of the next batch overlapped on a second stream" if args.prefetch else ""),
                           "points_per_step_per_gpu": n_points, "parallelism": "dp%d" % world,
@@ -405,7 +414,8 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    traffic = tj.get("kpconv_gather_fwd_bytes_per_launch", {}).get("%s:%d:%d" % (args.workload, h, ci))
+                    tkey = ("%s:%d:%d" if args.mode == "train" else "infer:%s:%d:%d") % (args.workload, h, ci)
+                    traffic = tj.get("kpconv_gather_fwd_bytes_per_launch", {}).get(tkey)
                 except Exception:
                     traffic = None
             deform = "deform" in args.workload
@@ -416,8 +426,14 @@ def main():
             from weasal_amd import _lib as _wl
             name = _C.create_string_buffer(256)
             _wl.check(_wl.lib().ws_kpconv_gather_fwd_variant(ci, 0, 0, 0, 1 if bf16 else 0, 1 if deform else 0, name, 256))
+            one_launch = (args.mode == "infer" and ci == 32 and not bf16 and not deform and fused.FUSED_INFER)
+            if one_launch:
+                kname = ("kpconv_gather_fwd_mfma_kernel<NT=2, MODE=0, DEF=false, VECROW=true, float, GS=2, CUT=false, FUSE=true> "
+                         "(gather AND the 15 Ci x Co contraction in one launch: ws_kpconv_layer_fwd_fused)")
+            else:
+                kname = name.value.decode()
             res["roofline"] = {"bound": "hbm",
-                               "kernel": name.value.decode() + " on N=%d queries, H=%d, Ci=%d" % (nq, h, ci)
+                               "kernel": kname + " on N=%d queries, H=%d, Ci=%d" % (nq, h, ci)
                                          + ("; rows from the deformable search radius: the kernel walks each (distance-sorted) row only "
                                             "up to the reach of the kernel points, B_fwd still counts every one of the H neighbours the "
                                             "reference gathers" if deform else ""),
@@ -432,7 +448,9 @@ def main():
                 # the whole layer B_fwd describes (gather + the contraction wf x W that follows it: two launches, `wf` makes
                 # a round trip through HBM between them), by HIP events from the start of the first to the end of the second
                 ml = float(np.mean(layer_ms[key]))
-                res["roofline"]["layer"] = {"what": "K3 gather + contraction [N,15Ci]x[15Ci,Co] of the same layer (two launches)",
+                res["roofline"]["layer"] = {"what": "K3 gather + contraction [N,15Ci]x[15Ci,Co] of the same layer (two launches)"
+                                                    if not one_launch else
+                                                    "the whole KPConv layer in one launch (gather + contraction + bias + LeakyReLU)",
                                             "avg_ms": ml, "achieved": bytes_alg / (ml * 1e-3) / 1e9,
                                             "frac": bytes_alg / (ml * 1e-3) / 1e9 / HBM_PEAK_GBS}
             # per-launch means of the KPConv gather kernels, grouped by layer (N varies by a few points from

@@ -430,6 +430,8 @@ typedef struct ws_kpblock {
     int32_t timed;                       /* 1: bracket the K3 launch with HIP events (ws_timer_*) */
     int32_t rows_sorted;                 /* 1: the rows of inds are sorted by distance from their query (radius search output):
                                             the gather stops at the reach of the kernel points (ws_kpconv_gather_fwd_ex) */
+    int32_t infer;                       /* 1: forward only -- no backward will follow: `wf` may be NULL and layers the fused
+                                            forward kernel covers (ws_kpconv_layer_fwd_fused) run as one launch */
 } ws_kpblock;
 
 int64_t ws_kpblock_fwd_scratch_bytes(const ws_kpblock* d);
@@ -589,6 +591,14 @@ int ws_kpconv_gather_bwd_geom_def(const float* q_pts, int64_t nq, const float* s
                                   const void* x, int32_t ci, const void* dwf, const float* kp4, int32_t k, const float* d_min_d2,
                                   float extent, const int32_t* order, float* d_kp4, int32_t rows_bf16, int32_t rows_sorted,
                                   void* stream);
+/* A whole forward KPConv layer in one launch, out [nq, co] = act(KPConv(x) + bias) with the contraction inside the gather
+ * kernel (models/blocks.py:278-374 + the BatchNormBlock bias / LeakyReLU of :556-563); rigid, linear influence, sum, f32,
+ * ci = co = 32 (else WS_ERR_UNSUPPORTED).  Forward only: nothing is kept for a backward pass (the weighted features
+ * never reach memory) -- the testers' forward passes, utils/tester_PseudoLabel.py:164. */
+int ws_kpconv_layer_fwd_fused(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                              const float* x, int32_t ci, const float* kernel_points, int32_t k, float extent,
+                              const int32_t* order, const float* weights, int32_t co, const float* bias, int32_t act, float slope,
+                              float* out, void* stream);
 /* name of the forward gather kernel the library launches for a layer of ci channels (mode 0 rigid, 1 deformable through the
  * generic entries, 2 deformable fast path): for reports, no device work */
 int ws_kpconv_gather_fwd_variant(int32_t ci, int32_t mode, int32_t influence, int32_t aggregation, int32_t rows_bf16,

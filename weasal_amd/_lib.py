@@ -122,6 +122,8 @@ SIGNATURES = {
                                                    _vp, _i32, _vp, _i32, _vp]),
     "ws_kpconv_gather_bwd_geom_def": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
                                                 _i32, _i32, _vp]),
+    "ws_kpconv_layer_fwd_fused": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _i32, _vp, _i32, _f32,
+                                           _vp, _vp]),
     "ws_kpconv_gather_fwd_variant": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.c_char_p, _i32]),
     "ws_p2p_regularizer_scratch_bytes": (_i64, [_i64]),
     "ws_p2p_regularizer_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp]),

@@ -17,6 +17,8 @@ extern "C" int ws_block_gates = 1;
 // Default 0 = off: measured on the DALES step the deep levels' products are bound by the matrix cores and by their
 // fixed launch / prologue latency, not by idle CUs -- 12.21 ms per step with the side stream, 12.11 without.
 extern "C" int64_t ws_block_side_rows = 0;
+// A/B switch (WEASAL_FUSED_INFER=0): forward-only blocks run gather + contraction as two launches like the training path
+extern "C" int ws_block_fused_infer = 1;
 
 namespace {
 
@@ -121,7 +123,7 @@ int check_kpblock(const ws_kpblock* d)
     WS_REQUIRE(d->nq >= 0 && d->ns >= 0 && d->h >= 1, "bad sizes nq=%lld ns=%lld h=%d", (long long)d->nq, (long long)d->ns, d->h);
     if (d->k != 15) return ws_fail(WS_ERR_UNSUPPORTED, "num_kernel_points=%d: K=15 only", d->k);
     WS_REQUIRE(d->in_dim >= 1 && d->conv_in >= 1 && d->conv_out >= 1 && d->out_dim >= 1, "bad widths");
-    WS_REQUIRE(d->q_pts && d->s_pts && d->inds && d->kernel_points && d->feat && d->wk && d->wf && d->out, "NULL argument");
+    WS_REQUIRE(d->q_pts && d->s_pts && d->inds && d->kernel_points && d->feat && d->wk && (d->wf || d->infer) && d->out, "NULL argument");
     WS_REQUIRE(d->w1 ? (d->x1 != nullptr) : (d->conv_in == d->in_dim), "unary1: x1 buffer missing or conv_in != in_dim");
     WS_REQUIRE(d->w2 ? (d->x2 != nullptr) : (d->out_dim == d->conv_out), "unary2: x2 buffer missing or out_dim != conv_out");
     WS_REQUIRE(!d->w2 || d->ws || d->in_dim == d->out_dim, "shortcut needs a projection (ws) when in_dim != out_dim");
@@ -166,12 +168,23 @@ int kpblock_fwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         rec.nq = nq; rec.h = d->h; rec.ci = d->conv_in;
         WS_HIP(hipEventRecord(rec.a, st));
     }
-    WS_TRY(ws_kpconv_gather_fwd_ex(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, x1, d->conv_in, d->kernel_points, d->k, nullptr, nullptr,
-                                   d->extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, d->order_q, d->wf, nullptr, 0, d->rows_sorted, st));
-    if (d->timed) WS_HIP(hipEventRecord(rec.b, st));
     float* x2 = d->w2 ? d->x2 : d->out;
-    WS_TRY(ws_gemm_xb_epilogue_strided(d->wf, nq, d->k * d->conv_in, (int64_t)d->k * d->conv_in, d->wk, d->conv_out, 1, d->conv_out,
-                                       d->bk, nullptr, 0, 1, d->slope, x2, d->conv_out, tmp, tmp_bytes, st));
+    // forward only and a layer the one-launch kernel covers: the contraction runs inside the gather, no `wf`
+    const bool one_launch = d->infer && d->conv_in == 32 && d->conv_out == 32 && !d->rows_sorted && ((uintptr_t)x1 & 15u) == 0 &&
+                            ((uintptr_t)d->wk & 15u) == 0 && ((uintptr_t)x2 & 15u) == 0 && ws_block_fused_infer;
+    if (one_launch) {
+        WS_TRY(ws_kpconv_layer_fwd_fused(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, x1, d->conv_in, d->kernel_points, d->k, d->extent,
+                                         d->order_q, d->wk, d->conv_out, d->bk, 1, d->slope, x2, st));
+        if (d->timed) WS_HIP(hipEventRecord(rec.b, st));
+    } else {
+        WS_REQUIRE(d->wf, "wf buffer missing");
+        WS_TRY(ws_kpconv_gather_fwd_ex(d->q_pts, nq, d->s_pts, ns, d->inds, d->h, x1, d->conv_in, d->kernel_points, d->k, nullptr,
+                                       nullptr, d->extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, d->order_q, d->wf, nullptr, 0,
+                                       d->rows_sorted, st));
+        if (d->timed) WS_HIP(hipEventRecord(rec.b, st));
+        WS_TRY(ws_gemm_xb_epilogue_strided(d->wf, nq, d->k * d->conv_in, (int64_t)d->k * d->conv_in, d->wk, d->conv_out, 1, d->conv_out,
+                                           d->bk, nullptr, 0, 1, d->slope, x2, d->conv_out, tmp, tmp_bytes, st));
+    }
     if (d->timed) {
         WS_HIP(hipEventCreate(&rec.c));
         WS_HIP(hipEventRecord(rec.c, st));

@@ -558,6 +558,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef WS_K3_GS
 #define WS_K3_GS 4
 #endif
+#ifndef WS_FUSE_GS
+#define WS_FUSE_GS 2      // steps in flight of the fused-contraction variant: its 60 registers of W leave room for fewer
+#endif
 
 template <int NT, typename T> struct RowLoad;
 template <int NT> struct RowLoad<NT, float> {
@@ -619,14 +622,33 @@ template <int NT> struct RowLoad<NT, bf16_t> {
 // the row stops there.  Exact -- the skipped terms are zeros -- and decisive where the rows come from the DEFORMABLE radius
 // (datasets/common.py:500-502: 2 r, while the kernel points reach 0.69 r + extent = 1.09 r: 84 % of a rigid offset
 // convolution's neighbours, ~60 % of a deformed one's, are outside every influence).
-template <int NT, int MODE, bool DEF, bool VECROW, typename T, int GSV = 0, bool CUT = false>
+// FUSE (forward only; MODE 0, NT = 2, f32, Ci = Co = 32: the level-0 layers, where the time is): the kernel contraction
+//   out[q, :] = act(wf[q] (1 x 15 Ci) . W (15 Ci x Co) + bias)                         (models/blocks.py:370-374, 556-563)
+// runs inside this kernel and `wf` never reaches memory (N x 15 x Ci x 4 B = 768 MB at enc1, written and read back by the
+// two-launch form -- which training keeps, dW needs wf).  The four waves of a workgroup gather one query each per
+// iteration into an LDS tile of 16 queries (four iterations); then every wave multiplies its QUARTER of the 480-deep
+// contraction -- that quarter of W lives in its registers for the whole launch (60 VGPRs: lane (j, kk) holds
+// W[120 w + 4 s + kk][16 n + j]) -- on v_mfma_f32_16x16x4_f32, the four partial [16 x 32] tiles are added through LDS
+// with the bias / LeakyReLU epilogue and stored as 16 output rows.  Tile rows are 484 floats apart: the A-operand reads
+// (lane (query, kk)) fall on 64 different banks.
+struct FuseArgs {
+    const float* w;        // [15 * ci, co] row-major (the module's weights [15, ci, co])
+    const float* bias;     // [co] or NULL
+    float slope;           // LeakyReLU slope (act != 0)
+    int act;
+    float* out;            // [nq, co]
+};
+
+template <int NT, int MODE, bool DEF, bool VECROW, typename T, int GSV = 0, bool CUT = false, bool FUSE = false>
 __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci,
     const float* __restrict__ kernel_points, const float* __restrict__ deformed_kp,
     const float* __restrict__ modulations, GeomParams g, T* __restrict__ wf,
-    float* __restrict__ min_d2, const int32_t* __restrict__ order)
+    float* __restrict__ min_d2, const int32_t* __restrict__ order, FuseArgs fz = FuseArgs{})
 {
+    static_assert(!FUSE || (MODE == 0 && NT == 2 && sizeof(T) == 4 && VECROW), "the fused contraction covers rigid 32 -> 32 f32 layers");
+    constexpr int TILE_LD = 484;
     constexpr int K = 15;
     constexpr int CB = 16 * NT;                                   // channels per block
     // steps whose loads are in flight together (per buffer; two buffers): more = deeper memory pipelining per wave,
@@ -677,7 +699,18 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     int vz;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
     const int64_t it0 = ibeg + wave;
-    if (it0 >= iend) return;
+    if (FUSE ? (ibeg >= iend) : (it0 >= iend)) return;            // (FUSE: workgroup-uniform -- every wave meets the barriers)
+    // FUSE: every wave runs the same number of iterations (dummy ones redo the workgroup's last query and store nothing)
+    const int64_t iend_u = FUSE ? ibeg + ((iend - ibeg + 3) / 4) * 4 : iend;
+    float wq[FUSE ? 30 : 1][2];
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int s_ = 0; s_ < 30; ++s_) {
+            wq[s_][0] = fz.w[(120 * wave + 4 * s_ + kk) * 32 + i];
+            wq[s_][1] = fz.w[(120 * wave + 4 * s_ + kk) * 32 + 16 + i];
+        }
+    }
+    int iter = 0;
     auto item_v = [&](int64_t it) -> int {                        // query of item `it`, in a VGPR (clamped past the end)
         const int64_t itc = it < iend ? it : iend - 1;
         return order ? order[itc + vz] : (int)itc + vz;
@@ -715,7 +748,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     q_xyz(qv1, q1x, q1y, q1z);
     int idx1 = chk(raw1);
 
-    for (int64_t item = it0; item < iend; item += 4) {
+    for (int64_t item = it0; item < iend_u; item += 4) {
         const int64_t q = qv0;                                    // (a VGPR value, the same in every lane)
         const int qv3 = item_v(item + 12);
         const int64_t raw2 = raw_idx(qv2);
@@ -938,7 +971,50 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
                 }
             }
             // D: lane (j = i, g = kk) holds kernel points 4 kk + r of its NT channels
-            if (chok) {
+            if constexpr (FUSE) {
+                __shared__ float tile_all[16 * TILE_LD];
+                __shared__ int tq_all[16];
+                const int slot = 4 * (iter & 3) + wave;
+                const bool valid = item < iend;
+                if (lane == 0) tq_all[slot] = valid ? (int)q : -1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * kk + r;
+                    if (k < K) *reinterpret_cast<float2*>(&tile_all[slot * TILE_LD + k * 32 + 2 * i]) = make_float2(acc[0][r], acc[1][r]);
+                }
+                if ((iter & 3) == 3 || item + 4 >= iend_u) {
+                    __shared__ float part_all[4 * 16 * 32];
+                    __syncthreads();                              // the tile is complete
+                    f32x4v o0 = f32x4v{0.f, 0.f, 0.f, 0.f}, o1 = o0;
+                    const float* arow = &tile_all[i * TILE_LD + 120 * wave + kk];
+#pragma unroll
+                    for (int s_ = 0; s_ < 30; ++s_) {
+                        const float a = arow[4 * s_];
+                        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wq[s_][0], o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wq[s_][1], o1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                 // D: lane (j, g) holds queries 4 g + r of output columns j, 16 + j
+                        part_all[(wave * 16 + 4 * kk + r) * 32 + i] = o0[r];
+                        part_all[(wave * 16 + 4 * kk + r) * 32 + 16 + i] = o1[r];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int e = threadIdx.x; e < 512; e += 256) {
+                        const int qs = e >> 5, c = e & 31;
+                        const int qq = tq_all[qs];
+                        float v = (part_all[(0 * 16 + qs) * 32 + c] + part_all[(1 * 16 + qs) * 32 + c]) +
+                                  (part_all[(2 * 16 + qs) * 32 + c] + part_all[(3 * 16 + qs) * 32 + c]);
+                        if (fz.bias) v += fz.bias[c];
+                        if (fz.act) v = v > 0.0f ? v : v * fz.slope;
+                        // slots this tile did not fill (a short last tile) keep the index of an older query: masked by the count
+                        const bool filled = qs < 4 * ((iter & 3) + 1);
+                        if (qq >= 0 && filled) fz.out[(int64_t)qq * 32 + c] = v;
+                    }
+                    __syncthreads();                              // tile and partials are free again
+                }
+                ++iter;
+            } else if (chok) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = 4 * kk + r;
@@ -2499,6 +2575,30 @@ int ws_kpconv_gather_bwd_geom_def(const float* q_pts, int64_t nq, const float* s
                                                 extent, order, dk, stream, rows_sorted);
     return gather_bwd_geom_def_impl<float>(q_pts, nq, s_pts, ns, inds, h, (const float*)x, ci, (const float*)dwf, kq, k, d_min_d2, extent,
                                            order, dk, stream, rows_sorted);
+}
+
+// Forward-only KPConv layer in ONE launch (inference: the testers' forward passes, utils/tester_PseudoLabel.py:164):
+// out = act(KPConv(x) + bias) for rigid / linear / sum layers of 32 -> 32 f32 channels -- the level-0 layers of the DALES
+// networks, where `wf` is largest (kpconv_gather_fwd_mfma_kernel<..., FUSE>).  Other shapes: WS_ERR_UNSUPPORTED (the caller
+// runs gather + contraction as two launches).
+int ws_kpconv_layer_fwd_fused(const float* q_pts, int64_t nq, const float* s_pts, int64_t ns, const int64_t* inds, int32_t h,
+                              const float* x, int32_t ci, const float* kernel_points, int32_t k, float extent,
+                              const int32_t* order, const float* weights, int32_t co, const float* bias, int32_t act, float slope,
+                              float* out, void* stream)
+{
+    int rc = check_common(q_pts, nq, s_pts, ns, h, ci, k, extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM);
+    if (rc) return rc;
+    if (ci != 32 || co != 32 || !aligned16(x) || !aligned16(weights) || !aligned16(out))
+        return ws_fail(WS_ERR_UNSUPPORTED, "fused forward layer: 32 -> 32 channels, 16-byte aligned rows (got %d -> %d)", ci, co);
+    if (nq == 0) return WS_OK;
+    WS_REQUIRE(inds && x && kernel_points && weights && out, "NULL argument");
+    WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
+    GeomParams g{extent, WS_INFLUENCE_LINEAR, WS_AGGREGATION_SUM, 0, 0, nullptr, 0.0f, nullptr, 0, nullptr, nullptr, 0};
+    FuseArgs fz{weights, bias, slope, act, out};
+    kpconv_gather_fwd_mfma_kernel<2, 0, false, true, float, WS_FUSE_GS, false, true><<<ws_grid(nq, 4), 256, 0, (hipStream_t)stream>>>(
+        q_pts, nq, s_pts, ns, inds, h, x, ci, kernel_points, nullptr, nullptr, g, nullptr, nullptr, order, fz);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
 }
 
 // Name of the forward gather kernel the dispatchers above launch for a layer (bench.py's roofline.kernel): same selection

@@ -19,6 +19,7 @@ from . import _lib, ops
 from ._lib import check, current_stream
 
 FUSED_BLOCKS = os.environ.get("WEASAL_FUSED_BLOCKS", "1") != "0"      # A/B switch (diagnostics, tests)
+FUSED_INFER = os.environ.get("WEASAL_FUSED_INFER", "1") != "0"        # A/B switch: forward-only 32 -> 32 layers in one launch
 _timed = False
 
 
@@ -48,7 +49,7 @@ class KPBlockDesc(C.Structure):
                 ("w1", _vp), ("b1", _vp), ("wk", _vp), ("bk", _vp), ("w2", _vp), ("b2", _vp), ("ws", _vp), ("bs", _vp),
                 ("feat", _vp), ("x1", _vp), ("wf", _vp), ("x2", _vp), ("pooled", _vp), ("arg", _vp), ("out", _vp),
                 ("dout", _vp), ("dfeat", _vp), ("dw1", _vp), ("db1", _vp), ("dwk", _vp), ("dbk", _vp), ("dw2", _vp),
-                ("db2", _vp), ("dws", _vp), ("timed", _i32), ("rows_sorted", _i32)]
+                ("db2", _vp), ("dws", _vp), ("timed", _i32), ("rows_sorted", _i32), ("infer", _i32)]
 
 
 class UpUnaryDesc(C.Structure):
@@ -67,6 +68,7 @@ def _bind():
     lib = _lib.lib()           # signatures: _lib.SIGNATURES (descriptors travel as void* = ctypes.byref(struct))
     if not _GATES_SET:         # diagnostics: WEASAL_BLOCK_GATES=0 = activation backward as separate passes
         C.c_int.in_dll(lib, "ws_block_gates").value = 0 if os.environ.get("WEASAL_BLOCK_GATES", "1") == "0" else 1
+        C.c_int.in_dll(lib, "ws_block_fused_infer").value = 1 if FUSED_INFER else 0
         if "WEASAL_BLOCK_SIDE_ROWS" in os.environ:      # 0 = weight-gradient products on the caller's stream
             C.c_int64.in_dll(lib, "ws_block_side_rows").value = int(os.environ["WEASAL_BLOCK_SIDE_ROWS"])
         _GATES_SET = True
@@ -104,7 +106,7 @@ def _scratch(nbytes, device):
 class _Geom:
     """geometry + widths of one block call (plain Python object carried through the autograd node)"""
     __slots__ = ("q_pts", "s_pts", "inds", "kp", "extent", "order_q", "order_s", "grid", "table", "in_dim", "conv_in",
-                 "conv_out", "out_dim", "strided", "slope", "has", "rows_sorted")
+                 "conv_out", "out_dim", "strided", "slope", "has", "rows_sorted", "infer")
 
     def fill(self, d):
         d.q_pts, d.nq = self.q_pts.data_ptr(), self.q_pts.shape[0]
@@ -121,6 +123,7 @@ class _Geom:
         d.in_dim, d.conv_in, d.conv_out, d.out_dim = self.in_dim, self.conv_in, self.conv_out, self.out_dim
         d.strided, d.slope = 1 if self.strided else 0, float(self.slope)
         d.rows_sorted = 1 if self.rows_sorted else 0
+        d.infer = 1 if self.infer else 0
 
 
 def _al(n):
@@ -139,7 +142,8 @@ class _KPBlockFn(torch.autograd.Function):
         nq, ns = g.q_pts.shape[0], g.s_pts.shape[0]
         k = g.kp.shape[0]
         # saved activations in ONE arena: x1 | wf | x2 | pooled | arg
-        sizes = [ns * g.conv_in if w1 is not None else 0, nq * k * g.conv_in, nq * g.conv_out if w2 is not None else 0,
+        fused_layer = g.infer and g.conv_in == 32 and g.conv_out == 32 and not g.rows_sorted and FUSED_INFER
+        sizes = [ns * g.conv_in if w1 is not None else 0, 0 if fused_layer else nq * k * g.conv_in, nq * g.conv_out if w2 is not None else 0,
                  nq * g.in_dim if (g.strided and w2 is not None) else 0, nq * g.in_dim if (g.strided and w2 is not None) else 0]
         offs, tot = [], 0
         for s in sizes:
@@ -154,7 +158,7 @@ class _KPBlockFn(torch.autograd.Function):
         d.w1, d.b1, d.wk, d.bk, d.w2, d.b2, d.ws, d.bs = _p(w1), _p(b1), wkc.data_ptr(), _p(bk), _p(w2), _p(b2), _p(wsc), _p(bsc)
         d.feat = feat.data_ptr()
         d.x1 = base + 4 * offs[0] if sizes[0] else None
-        d.wf = base + 4 * offs[1]
+        d.wf = base + 4 * offs[1] if sizes[1] else None
         d.x2 = base + 4 * offs[2] if sizes[2] else None
         d.pooled = base + 4 * offs[3] if sizes[3] else None
         d.arg = base + 4 * offs[4] if sizes[4] else None
@@ -227,6 +231,7 @@ def _geometry(conv, q_pts, s_pts, inds, strided):
     g.table = None
     g.strided = strided
     g.rows_sorted = ops.rows_cutoff_pays(g.inds, conv.radius)      # searched with the deformable radius: stop at the kernel's reach
+    g.infer = not torch.is_grad_enabled()      # a forward pass nobody will differentiate (the testers' loops run under no_grad)
     return g
 
 
