@@ -79,18 +79,13 @@ __global__ __launch_bounds__(CT_ROWS) void contrast_fwd_kernel(const float* __re
         mytag[b] = ((int)lbl[ic] << 1) | (certain[ic] ? 1 : 0);
         m[b] = -3.0e38f; E[b] = 0.0f; P[b] = 0.0f; S[b] = 0.0f;
     }
-    for (int j = 0; j < s; ++j) {
-        float sj[CP];
-#pragma unroll
-        for (int cc = 0; cc < CP; ++cc) sj[cc] = tb.xs[j][cc];
-#pragma unroll
-        for (int b = 0; b < RB; ++b) m[b] = fmaxf(m[b], dotc<CP>(o[b], sj));
-    }
-    // the maximum of the quotients is the quotient of the maximum (T > 0); inside the loops the division by T
-    // is a multiplication by 1/T and exp is the hardware exp2 (both well inside the 1e-4 bar)
+    // ONE pass over the slice (round 3; the first form took the row maximum in a pass of its own).  The rows are unit
+    // vectors, so every logit lies in [-1/T, 1/T]: the sums are taken against that bound,
+    //   E' = sum_j use_ij exp(mul_ij - 1/T),   S' = sum_j pos_ij mul_ij,   m = max_j mul_ij   (over ALL columns, :484-486),
+    // and rebased on the true maximum afterwards: E = E' exp(1/T - m), S = S' - P m.  exp(mul - 1/T) >= exp(-2/T) = 2e-9
+    // at T = 0.1: no underflow, the same relative rounding as the two-pass form.  (The maximum cannot be dropped
+    // altogether: eps enters log(E + eps) after the subtraction, :490.)
     const float inv_t = 1.0f / temperature;
-#pragma unroll
-    for (int b = 0; b < RB; ++b) m[b] = m[b] / temperature;
     for (int j = 0; j < s; ++j) {
         float sj[CP];
 #pragma unroll
@@ -98,13 +93,19 @@ __global__ __launch_bounds__(CT_ROWS) void contrast_fwd_kernel(const float* __re
         const int tg = tb.tag[j], sid = tb.idx[j];
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-            const float lg = dotc<CP>(o[b], sj) * inv_t - m[b];
+            const float mul = dotc<CP>(o[b], sj) * inv_t;
+            m[b] = fmaxf(m[b], mul);
             const bool use = sid != (int)i[b] && ((tg ^ mytag[b]) & 1) == 0;
             const bool pos = use && tg == mytag[b];
-            E[b] += use ? __expf(lg) : 0.0f;
+            E[b] += use ? __expf(mul - inv_t) : 0.0f;
             P[b] += pos ? 1.0f : 0.0f;
-            S[b] += pos ? lg : 0.0f;
+            S[b] += pos ? mul : 0.0f;
         }
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+        E[b] *= __expf(inv_t - m[b]);
+        S[b] -= P[b] * m[b];
     }
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
