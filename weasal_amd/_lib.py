@@ -155,7 +155,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         # diagnostics switches of the library (integer globals), settable from the environment for A/B runs
-        for env, sym in (("WEASAL_GEMM_SPLIT", "ws_gemm_split"), ("WEASAL_K4G_ROWS", "ws_kpconv_grid_rows")):
+        for env, sym in (("WEASAL_GEMM_SPLIT", "ws_gemm_split"), ("WEASAL_K4G_ROWS", "ws_kpconv_grid_rows"),
+                         ("WEASAL_NB_BUCKET", "ws_nb_bucket128")):
             if env in os.environ:
                 C.c_int.in_dll(handle, sym).value = int(os.environ[env])
         _lib = handle

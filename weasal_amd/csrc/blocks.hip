@@ -19,6 +19,8 @@ extern "C" int ws_block_gates = 1;
 extern "C" int64_t ws_block_side_rows = 0;
 // A/B switch (WEASAL_FUSED_INFER=0): forward-only blocks run gather + contraction as two launches like the training path
 extern "C" int ws_block_fused_infer = 1;
+// A/B switch (WEASAL_POOL_ORDER=0): the strided blocks' max-pool walks its rows by index instead of in cell order
+extern "C" int ws_block_pool_order = 1;
 
 namespace {
 
@@ -194,7 +196,8 @@ int kpblock_fwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     const float* sc_in = d->feat;
     if (d->strided) {
         if (arg_bytes(d))
-            WS_TRY(ws_priv_max_pool_fwd_u8(d->feat, ns, d->in_dim, d->inds, nq, d->h, d->pooled, reinterpret_cast<uint8_t*>(d->arg), st));
+            WS_TRY(ws_priv_max_pool_fwd_u8(d->feat, ns, d->in_dim, d->inds, nq, d->h, d->pooled, reinterpret_cast<uint8_t*>(d->arg),
+                                           ws_block_pool_order ? d->order_q : nullptr, st));
         else
             WS_TRY(ws_max_pool_fwd(d->feat, ns, d->in_dim, d->inds, nq, d->h, d->pooled, d->arg, st));
         sc_in = d->pooled;
@@ -288,7 +291,7 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
                 WS_REQUIRE(d->t_offsets && d->t_pairs, "strided block backward needs the transposed table");
                 if (arg_bytes(d))
                     WS_TRY(ws_priv_max_pool_bwd_u8(dsc, reinterpret_cast<const uint8_t*>(d->arg), nq, d->h, d->in_dim, d->t_offsets,
-                                                   d->t_pairs, ns, dfsc, st));
+                                                   d->t_pairs, ns, dfsc, ws_block_pool_order ? d->order_s : nullptr, st));
                 else
                     WS_TRY(ws_max_pool_bwd(dsc, d->arg, nq, d->h, d->in_dim, d->t_offsets, d->t_pairs, ns, dfsc, st));
                 sc_res = dfsc;

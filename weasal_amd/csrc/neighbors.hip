@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
 //    of nine dependent round trips;
 //  * hits are compacted through the wave's LDS slab, then each lane takes two keys (i and i+64) and
 //    finds their sorted positions by counting the smaller keys (LDS broadcast reads).
-template <typename OutT>
+template <typename OutT, bool BUCKET = false>
 __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict__ queries, int64_t nq,
                                                           const CloudGrid* __restrict__ grids, int nb,
                                                           const int32_t* __restrict__ cell_start,
@@ -349,7 +349,56 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
         const unsigned long long a = lane < cnt ? slab[lane] : ~0ull;
         const unsigned long long bkey = lane + 64 < cnt ? slab[lane + 64] : ~0ull;
         int ra = 0, rb = 0;
-        if (cnt <= 64) {
+        if constexpr (BUCKET) {
+            // round 3: one level of buckets in front of the counting (as in nb_fill_wide_kernel): 64 buckets over [0, r^2),
+            // bucket = (int)(d2 * 64 / r^2) is monotone in d2, so rank = keys in smaller buckets + smaller keys of the own
+            // bucket -- ~1 key per bucket: a 64-wide scan and a two- or three-step count instead of cnt (60 .. 90) steps
+            __shared__ int hist_all[4][64];
+            __shared__ unsigned char member_all[4][128];
+            int* hist = hist_all[wave];
+            unsigned char* member = member_all[wave];
+            hist[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float bscale = 64.0f / r2;
+            const int ba = min(63, (int)(__uint_as_float((unsigned)(a >> 32)) * bscale));
+            const int bb = min(63, (int)(__uint_as_float((unsigned)(bkey >> 32)) * bscale));
+            int pa = 0, pb = 0;
+            if (lane < cnt) pa = atomicAdd(&hist[ba], 1);
+            if (lane + 64 < cnt) pb = atomicAdd(&hist[bb], 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int own = hist[lane];
+            int incl = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                incl += lane >= o ? t : 0;
+            }
+            int maxb = own;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) maxb = max(maxb, __shfl_xor(maxb, o, 64));
+            maxb = __builtin_amdgcn_readfirstlane(maxb);
+            __shared__ int start_all[4][64];
+            int* start = start_all[wave];
+            start[lane] = incl - own;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int sa = start[ba], sb = start[bb];
+            const int na = lane < cnt ? hist[ba] : 0, nbk = lane + 64 < cnt ? hist[bb] : 0;
+            if (lane < cnt) member[sa + pa] = (unsigned char)lane;
+            if (lane + 64 < cnt) member[sb + pb] = (unsigned char)(lane + 64);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            ra = sa; rb = sb;
+            for (int t = 0; t < maxb; ++t) {
+                const bool oka = t < na, okb = t < nbk;
+                const unsigned long long ka = slab[member[oka ? sa + t : 0]];
+                const unsigned long long kb = slab[member[okb ? sb + t : 0]];
+                ra += (oka && ka < a) ? 1 : 0;
+                rb += (okb && kb < bkey) ? 1 : 0;
+            }
+        } else if (cnt <= 64) {
 #pragma unroll 8
             for (int i = 0; i < cnt; ++i) ra += slab[i] < a ? 1 : 0;
         } else {
@@ -572,6 +621,9 @@ struct DevBuf {
 
 }  // namespace
 
+// A/B switch (WEASAL_NB_BUCKET=0/1): bucketed rank in the <= 128-neighbour search
+extern "C" int ws_nb_bucket128 = 1;
+
 struct ws_neighbors_ws {
     DevBuf<CloudGrid> grids;
     DevBuf<float> bbox;
@@ -755,12 +807,12 @@ static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* 
                                                                ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx, kl);  \
     } while (0)
     if (cap <= 128) {
-        if (out_i32)
-            nb_fill128_kernel<int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
-                                                             ws->sorted.p, ws->r2, ws->ns, width, qo, out_i32, cn, mx, kl);
-        else
-            nb_fill128_kernel<int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
-                                                             ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx, kl);
+#define WS_NB128(OT, BK, OUT)                                                                                                \
+    nb_fill128_kernel<OT, BK><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p, ws->sorted.p, \
+                                                    ws->r2, ws->ns, width, qo, OUT, cn, mx, kl)
+        if (ws_nb_bucket128) { if (out_i32) WS_NB128(int32_t, true, out_i32); else WS_NB128(int64_t, true, out_i64); }
+        else { if (out_i32) WS_NB128(int32_t, false, out_i32); else WS_NB128(int64_t, false, out_i64); }
+#undef WS_NB128
     }
     else if (cap <= 1024) {
         if (out_i32)

@@ -24,16 +24,22 @@ __device__ __forceinline__ int4 load_arg4(const uint8_t* p)
 template <int G, typename T, typename AT = int32_t>
 __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restrict__ x, int64_t ns, int c,
                                                                 const int64_t* __restrict__ inds, int64_t nq, int h,
-                                                                T* __restrict__ out, AT* __restrict__ arg)
+                                                                T* __restrict__ out, AT* __restrict__ arg,
+                                                                const int32_t* __restrict__ order = nullptr)
 {
+    // order (optional): a spatially coherent permutation of the queries (the cell order of their level's search).  The
+    // pooled points come out of the grid subsampling in hash-table order: walked by index, consecutive queries gather
+    // rows from all over the cloud and every 512-byte row is fetched ~3.6 times from HBM (PMC, round 2); in cell order
+    // the waves of a workgroup share their neighbourhoods in L2.
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane % G, slot = lane / G;
     int64_t ibeg, iend;
     ws_block_range(ws_ceil_div_dev(nq, S), ibeg, iend);
     for (int64_t grp = ibeg + wave; grp < iend; grp += 4) {
-        const int64_t q = grp * S + slot;
-        const bool qok = q < nq;
+        const int64_t qi = grp * S + slot;
+        const bool qok = qi < nq;
+        const int64_t q = (qok && order) ? (int64_t)order[qi] : qi;
         for (int c0 = 0; c0 < c; c0 += 4 * G) {
             const int ch = c0 + 4 * j;
             const bool ok = qok && ch < c;
@@ -102,7 +108,7 @@ template <int G, typename T, typename AT = int32_t>
 __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restrict__ dy, const AT* __restrict__ arg,
                                                                 int h, int c, const int32_t* __restrict__ t_offsets,
                                                                 const int32_t* __restrict__ t_pairs, int64_t ns,
-                                                                T* __restrict__ dx)
+                                                                T* __restrict__ dx, const int32_t* __restrict__ order = nullptr)
 {
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -110,8 +116,9 @@ __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restri
     int64_t ibeg, iend;
     ws_block_range(ws_ceil_div_dev(ns, S), ibeg, iend);
     for (int64_t grp = ibeg + wave; grp < iend; grp += 4) {
-        const int64_t s = grp * S + slot;
-        const bool sok = s < ns;
+        const int64_t si = grp * S + slot;
+        const bool sok = si < ns;
+        const int64_t s = (sok && order) ? (int64_t)order[si] : si;       // supports in their level's cell order (see the forward)
         const int beg = sok ? t_offsets[s] : 0, end = sok ? t_offsets[s + 1] : 0;
         for (int c0 = 0; c0 < c; c0 += 4 * G) {
             const int ch = c0 + 4 * j;
@@ -264,27 +271,27 @@ int max_pool_bwd_impl(const T* dy, const int32_t* arg, int64_t nq, int32_t h, in
 
 // the block calls' private form: arg-max record in bytes (h <= 255, c % 4 == 0, aligned rows: the caller checks)
 int max_pool_fwd_u8_impl(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, float* out, uint8_t* arg,
-                         hipStream_t st)
+                         const int32_t* order, hipStream_t st)
 {
     if (nq == 0) return WS_OK;
-    if (c <= 16) max_pool_fwd_vec_kernel<4, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 16), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (c <= 32) max_pool_fwd_vec_kernel<8, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 8), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (c <= 64) max_pool_fwd_vec_kernel<16, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 4), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (c <= 128) max_pool_fwd_vec_kernel<32, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 2), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else max_pool_fwd_vec_kernel<64, float, uint8_t><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    if (c <= 16) max_pool_fwd_vec_kernel<4, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 16), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
+    else if (c <= 32) max_pool_fwd_vec_kernel<8, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 8), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
+    else if (c <= 64) max_pool_fwd_vec_kernel<16, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 4), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
+    else if (c <= 128) max_pool_fwd_vec_kernel<32, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 2), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
+    else max_pool_fwd_vec_kernel<64, float, uint8_t><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
 
 int max_pool_bwd_u8_impl(const float* dy, const uint8_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
-                         const int32_t* t_pairs, int64_t ns, float* dx, hipStream_t st)
+                         const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order, hipStream_t st)
 {
     (void)nq;
     if (ns == 0) return WS_OK;
-    if (c <= 32) max_pool_bwd_vec_kernel<8, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 8), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else if (c <= 64) max_pool_bwd_vec_kernel<16, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 4), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else if (c <= 128) max_pool_bwd_vec_kernel<32, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 2), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else max_pool_bwd_vec_kernel<64, float, uint8_t><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    if (c <= 32) max_pool_bwd_vec_kernel<8, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 8), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order);
+    else if (c <= 64) max_pool_bwd_vec_kernel<16, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 4), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order);
+    else if (c <= 128) max_pool_bwd_vec_kernel<32, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 2), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order);
+    else max_pool_bwd_vec_kernel<64, float, uint8_t><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
@@ -371,15 +378,15 @@ int ws_closest_pool_bwd_bf16(const uint16_t* dy, int64_t nq, int32_t h, int32_t 
 // private to the library (declared in ws_common.h, not part of include/weasal_hip.h): the block calls keep their arg-max
 // record in bytes.  Preconditions (checked by the caller): h <= 255, c % 4 == 0, 16-byte aligned rows, 4-byte aligned arg.
 int ws_priv_max_pool_fwd_u8(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, float* out,
-                            uint8_t* arg, void* stream)
+                            uint8_t* arg, const int32_t* order_q, void* stream)
 {
-    return max_pool_fwd_u8_impl(x, ns, c, inds, nq, h, out, arg, (hipStream_t)stream);
+    return max_pool_fwd_u8_impl(x, ns, c, inds, nq, h, out, arg, order_q, (hipStream_t)stream);
 }
 
 int ws_priv_max_pool_bwd_u8(const float* dy, const uint8_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
-                            const int32_t* t_pairs, int64_t ns, float* dx, void* stream)
+                            const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order_s, void* stream)
 {
-    return max_pool_bwd_u8_impl(dy, arg, nq, h, c, t_offsets, t_pairs, ns, dx, (hipStream_t)stream);
+    return max_pool_bwd_u8_impl(dy, arg, nq, h, c, t_offsets, t_pairs, ns, dx, order_s, (hipStream_t)stream);
 }
 
 }  // extern "C"
