@@ -320,7 +320,10 @@ def test_split_bf16_products_are_fp32_accurate(gpu, m, k, n):
     splits) against float64, next to the default f32-input MFMA kernels on the same operands: its error is not larger"""
     import ctypes
     from weasal_amd import _lib, ops
-    sw = ctypes.c_int.in_dll(_lib.lib(), "ws_gemm_split")
+    try:
+        sw = ctypes.c_int.in_dll(_lib.lib(), "ws_gemm_split")
+    except ValueError:
+        pytest.skip("lab-only kernels (make CXXFLAGS+=-DWS_LAB_SPLIT_GEMM): not compiled into the product library")
     torch.manual_seed(m + k)
     x = torch.randn(m, k, device=gpu) * torch.exp(torch.randn(m, 1, device=gpu))       # rows of very different scale
     b = torch.randn(k, n, device=gpu) / k ** 0.5

@@ -158,7 +158,10 @@ def lib():
         for env, sym in (("WEASAL_GEMM_SPLIT", "ws_gemm_split"), ("WEASAL_K4G_ROWS", "ws_kpconv_grid_rows"),
                          ("WEASAL_NB_BUCKET", "ws_nb_bucket128")):
             if env in os.environ:
-                C.c_int.in_dll(handle, sym).value = int(os.environ[env])
+                try:
+                    C.c_int.in_dll(handle, sym).value = int(os.environ[env])
+                except ValueError:
+                    raise WeasalHipError("%s is set but this build of libweasal_hip.so has no switch %s (a lab-only option)" % (env, sym))
         _lib = handle
     return _lib
 

@@ -367,6 +367,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
         xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope, gate);
 }
 
+// The three-way bf16 split products (gemm_xb3, gemm_xty2<..., SPLIT>) are a LAB build only (-DWS_LAB_SPLIT_GEMM; tools/
+// split_gemm_lab.py): measured in round 2 (15 % per product, 2.3 % per step, fp32-accurate), not the reference's
+// arithmetic behind a line that says f32 -- they are not compiled into the product library.
+#ifdef WS_LAB_SPLIT_GEMM
 // ---------------------------------------------------------------------------------------------
 // gemm_xb3: the same product, fp32 in and out, with every fp32 PRODUCT evaluated on the bf16 MFMA from exact three-way
 // splits of both operands:  x = xh + xm + xl,  w = wh + wm + wl  (bf16 pieces: xh = bf16(x), xm = bf16(x - xh),
@@ -543,6 +547,8 @@ __global__ __launch_bounds__(256) void gemm_xb3_kernel(
     else
         xb_rows_epilogue<NT>(acc, row, m, n0, n, h, y, ldy, bias, residual, ldr, act, slope, gate);
 }
+
+#endif  // WS_LAB_SPLIT_GEMM
 
 // y = act(sum_z partial[z] + bias + residual): the epilogue of a split-K gemm_xb2 (fixed order over z)
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ partial, int splits, int64_t m, int n,
@@ -1078,11 +1084,13 @@ extern "C" {
 // diagnostic switches of tools/gemm_lab.cpp (not part of the drop-in surface of include/weasal_hip.h)
 int ws_gemm_wave_cols = 0;  // forced wave grid of gemm_xb2 (column groups 1 / 2), 0 = automatic
 int ws_gemm_variant = 2;    // 1 = LDS-staged tiles (gemm_xb / gemm_xty), 2 = operands straight from global memory
+#ifdef WS_LAB_SPLIT_GEMM
 int ws_gemm_split = 0;      // 0 = the f32-input MFMA (default: the benchmark's fp32 numbers are measured on it);
                             // 1 = y = x b with every fp32 product as six bf16 MFMA partial products of exact three-way splits
                             // (gemm_xb3; WEASAL_GEMM_SPLIT=1): error against float64 not above the f32-input kernels, 15 % less
                             // time per product at the tall shapes, 2.3 % per DALES training step (12.26 -> 11.98 ms).  Opt-in:
                             // the gain does not pay for a second arithmetic behind the label "fp32".  2 = the same with 64-column tiles
+#endif
 
 int64_t ws_gemm_xb_scratch_bytes(int64_t m, int32_t k, int32_t n)
 {
@@ -1133,6 +1141,7 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
             splitk_epilogue_kernel<<<ws_grid(m * (n / 4), 256), 256, 0, st>>>(part, splits, m, n, y, ldy, bias, residual, ldr, \
                                                                               act, slope, gate);                \
     } while (0)
+#ifdef WS_LAB_SPLIT_GEMM
         if (ws_gemm_split) {
             // fp32 products as six bf16 MFMA partial products (gemm_xb3): 128 rows x 32 NT columns per workgroup
 #define WS_XB3(NTV)                                                                                             \
@@ -1163,6 +1172,7 @@ static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const
             WS_LAUNCH_CHECK();
             return WS_OK;
         }
+#endif  // WS_LAB_SPLIT_GEMM
         const int64_t tiles = ws_ceil_div(m, 32);
         int wn = tiles >= 2048 ? 1 : 2;
         if (ws_gemm_wave_cols) wn = ws_gemm_wave_cols;
@@ -1306,12 +1316,18 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
         const int kt = (k > 32 && al8x) ? 2 : 1, nt = (n > 32 && al8y) ? 2 : 1;
         const int wk = k > 32 * kt ? 2 : 1;
         const int wn = (n > 32 * nt && wk == 1) || (n > 32 * nt && k > 32 * kt) ? 2 : 1;
+#ifdef WS_LAB_SPLIT_GEMM
+#define WS_XTY2_SPLIT(KTV, NTV, WKV, WNV)                                                                             \
+        if (ws_gemm_split)                                                                                            \
+            gemm_xty2_kernel<KTV, NTV, WKV, WNV, float, true><<<g3, 256, 0, st>>>(x, m, k, ldx, y, n, ldy, partial, chunk); \
+        else
+#else
+#define WS_XTY2_SPLIT(KTV, NTV, WKV, WNV)
+#endif
 #define WS_XTY2(KTV, NTV, WKV, WNV)                                                                                   \
     do {                                                                                                              \
         const dim3 g3(chunks, (unsigned)ws_ceil_div(k, 32 * KTV * WKV), (unsigned)ws_ceil_div(n, 32 * NTV * WNV));    \
-        if (ws_gemm_split)                                                                                            \
-            gemm_xty2_kernel<KTV, NTV, WKV, WNV, float, true><<<g3, 256, 0, st>>>(x, m, k, ldx, y, n, ldy, partial, chunk); \
-        else                                                                                                          \
+        WS_XTY2_SPLIT(KTV, NTV, WKV, WNV)                                                                             \
             gemm_xty2_kernel<KTV, NTV, WKV, WNV><<<g3, 256, 0, st>>>(x, m, k, ldx, y, n, ldy, partial, chunk);        \
     } while (0)
 #define WS_XTY2_W(KTV, NTV)                          \
