@@ -315,6 +315,11 @@ def main():
     # tree and the autograd graphs for 80-90 ms at about the 17th step of a fresh process
     # (tools/stall_diag.py) -- a host stall, unrelated to the kernels, that drains the launch queue.
     from weasal_amd.trainer import freeze_gc
+    if os.environ.get("WEASAL_TRAIN_STREAM_PRIORITY", "0") != "0":
+        # experiment: the training work on a high-priority stream (the pyramid builders keep normal priority)
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(hp)
     for i in range(max(0, 12 - args.warmup)):
         step(i)
     torch.cuda.synchronize()

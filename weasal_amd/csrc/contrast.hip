@@ -276,6 +276,17 @@ int64_t slice_chunk(int64_t n)
 
 }  // namespace
 
+// the matrix-core form of the same three passes (contrast_mfma.hip), the default
+extern "C" int ws_contrast_variant;
+extern "C" int ws_contrast_mfma_fwd(const float* on, int64_t n, int32_t c, const float* xs, int32_t s, const int64_t* slc_idx,
+                                    const uint8_t* certain, const int64_t* lbl, float temperature, float eps, float* loss,
+                                    float* rowmax, float* den, float* npos, void* stream);
+extern "C" int64_t ws_contrast_mfma_bwd_scratch_bytes(int64_t n, int32_t c, int32_t s);
+extern "C" int ws_contrast_mfma_bwd(const float* on, int64_t n, int32_t c, const float* xs, int32_t s, const int64_t* slc_idx,
+                                    const uint8_t* certain, const int64_t* lbl, float temperature, const float* rowmax,
+                                    const float* den, const float* npos, const float* g, float* d_on, float* d_xs, void* scratch,
+                                    void* stream);
+
 extern "C" {
 
 int ws_contrast_rows_fwd(const float* on, int64_t n, int32_t c, const float* xs, int32_t s, const int64_t* slc_idx,
@@ -287,6 +298,8 @@ int ws_contrast_rows_fwd(const float* on, int64_t n, int32_t c, const float* xs,
     WS_REQUIRE(n < (1ll << 31), "n exceeds int32");
     if (n == 0) return WS_OK;
     WS_REQUIRE(on && xs && slc_idx && certain && lbl && loss && rowmax && den && npos, "NULL argument");
+    if (ws_contrast_variant == 2)
+        return ws_contrast_mfma_fwd(on, n, c, xs, s, slc_idx, certain, lbl, temperature, eps, loss, rowmax, den, npos, stream);
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)ws_ceil_div(n, CT_ROWS * RB);
 #define WS_CF(CPV) contrast_fwd_kernel<CPV><<<grid, CT_ROWS, 0, st>>>(on, n, c, xs, s, slc_idx, certain, lbl, temperature, eps, loss, rowmax, den, npos)
@@ -301,7 +314,9 @@ int ws_contrast_rows_fwd(const float* on, int64_t n, int32_t c, const float* xs,
 
 int64_t ws_contrast_rows_bwd_scratch_bytes(int64_t n, int32_t c, int32_t s)
 {
-    return ws_ceil_div(n > 0 ? n : 1, slice_chunk(n)) * (int64_t)s * c * (int64_t)sizeof(float);
+    const int64_t a = ws_ceil_div(n > 0 ? n : 1, slice_chunk(n)) * (int64_t)s * c * (int64_t)sizeof(float);
+    const int64_t b = ws_contrast_mfma_bwd_scratch_bytes(n, c, s);
+    return a > b ? a : b;          // (either variant may run)
 }
 
 int ws_contrast_rows_bwd(const float* on, int64_t n, int32_t c, const float* xs, int32_t s, const int64_t* slc_idx,
@@ -318,6 +333,8 @@ int ws_contrast_rows_bwd(const float* on, int64_t n, int32_t c, const float* xs,
         return WS_OK;
     }
     WS_REQUIRE(on && xs && slc_idx && certain && lbl && rowmax && den && npos && g && d_on && scratch, "NULL argument");
+    if (ws_contrast_variant == 2)
+        return ws_contrast_mfma_bwd(on, n, c, xs, s, slc_idx, certain, lbl, temperature, rowmax, den, npos, g, d_on, d_xs, scratch, stream);
     const unsigned grid = (unsigned)ws_ceil_div(n, CT_ROWS * RB);
     const int64_t chunk = slice_chunk(n);
     const int chunks = (int)ws_ceil_div(n, chunk);
