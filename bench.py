@@ -49,6 +49,29 @@ def u_fwd(n, ns, h, ci, co, es=4):
     return 8 * n * h + ns * (12 + es * ci) + n * (12 + es * co) + 4 * 15 * ci * co
 
 
+def rows_inside_reach(net, cfg, inp, limits, h, ci):
+    """mean number of neighbours per query that lie within the reach (largest kernel-point norm + influence extent) of the
+    first KPConv with `ci` input channels whose index matrix has `h` columns -- what a sorted-row cutoff launch gathers"""
+    import torch
+    from weasal_amd import pyramid
+    from weasal_amd.blocks import KPConv
+    pts, feats, labels, lens = inp
+    b = pyramid.build_batch(cfg, pts, feats, labels, lens, limits)
+    lvl = [l for l, m in enumerate(b.neighbors) if m.shape[1] == h]
+    mods = [m for m in net.modules() if isinstance(m, KPConv) and m.in_channels == ci and not m.deformable]
+    if not lvl or not mods:
+        return None
+    l, m = lvl[0], mods[0]
+    reach = float(m.kernel_points.norm(dim=1).max()) + float(m.KP_extent)
+    q = b.points[l]
+    sp = torch.cat([q, torch.full((1, 3), 1e6, device=q.device)])
+    tot = 0
+    for a in range(0, q.shape[0], 32768):
+        d2 = ((sp[b.neighbors[l][a:a + 32768]] - q[a:a + 32768, None, :]) ** 2).sum(-1)
+        tot += int((d2 <= reach * reach).sum())
+    return tot / q.shape[0]
+
+
 class KernelTimer:
     """HIP-event timing of selected launches on torch's current stream (= the launch stream)"""
 
@@ -413,6 +436,15 @@ def main():
             ms_k, count = fwd[key]
             _, nq, h, ci = key
             bytes_alg = b_fwd(nq, h, ci, ci, es)
+            deform = "deform" in args.workload
+            h_reach = None
+            if deform:
+                # rows searched with the deformable radius, walked only up to the kernel's reach (sorted-row cutoff): price the
+                # launch on the neighbours INSIDE the reach (the ones with a non-zero influence, which any implementation has
+                # to gather), not on all H columns -- otherwise skipped columns would count as bytes moved
+                h_reach = rows_inside_reach(net, cfg, inputs[0], wl["limits"], h, ci)
+                if h_reach is not None:
+                    bytes_alg = int(nq * h_reach * (8 + 12 + es * ci) + nq * (12 + es * ci) + 4 * 15 * ci * ci + 180)
             achieved = bytes_alg / (ms_k * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(REPO, "profiles", "traffic.json")
@@ -423,7 +455,6 @@ def main():
                     traffic = tj.get("kpconv_gather_fwd_bytes_per_launch", {}).get(tkey)
                 except Exception:
                     traffic = None
-            deform = "deform" in args.workload
             # the kernel the library's dispatcher launches for this layer (ws_kpconv_gather_fwd_variant: the same selection
             # rules as the launch).  In the deformable workloads the timed launch is the rigid OFFSET convolution of the
             # first deformable block; rows searched with the deformable radius take the sorted-row cutoff.
@@ -440,8 +471,8 @@ def main():
             res["roofline"] = {"bound": "hbm",
                                "kernel": kname + " on N=%d queries, H=%d, Ci=%d" % (nq, h, ci)
                                          + ("; rows from the deformable search radius: the kernel walks each (distance-sorted) row only "
-                                            "up to the reach of the kernel points, B_fwd still counts every one of the H neighbours the "
-                                            "reference gathers" if deform else ""),
+                                            "up to the reach of the kernel points (%.1f of the %d columns on average): the algorithmic bytes "
+                                            "count those neighbours only" % (h_reach, h) if deform and h_reach is not None else ""),
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "achieved_is": "SURVEY 8d logical-gather bytes B_fwd / launch time (every neighbour reference "

@@ -323,6 +323,32 @@ int ws_contrast_rows_bwd(const float* on, int64_t n, int32_t c, const float* xs,
                          const float* den, const float* npos, const float* g, float* d_on, float* d_xs, void* scratch,
                          void* stream);
 
+/* The rest of KPFCNN.contrast_loss around the [N, slc_con] part (models/architectures.py:425-454 before it, :475-476 the
+ * normalisation, :498-504 after it), so that the whole loss is a few launches and never synchronises with the host.
+ * head_fwd: x [n, c] logits (row stride ldx), labels [n] int64 (values >= 10 = unlabelled, :430-433), threshold
+ *   (config.contrast_thd / 100).  Writes on [n,c] = F.normalize(x) (:475), inv_norm [n] = 1 / max(|x|, 1e-12), certain [n]
+ *   uint8 = (max softmax > threshold) | labelled, lbl [n] int64 = the label where given else the arg-max class, then draws the
+ *   slice: slot j of s takes the r_j-th valid point (0-based, in index order), r_j = r_given[j], or from the uniforms u [s] as
+ *   floor(u_j * num_valid) -- with fewer than s valid points slot j < num_valid takes point j (:450-454) -- clamped to
+ *   num_valid - 1; slc_idx [s] int64 and xs [s,c] = on[slc_idx] (:476).  state [2] int32: number of valid points, and the
+ *   tail's arrival counter (zeroed here).  No valid point: slc_idx = n - 1 everywhere and the tail returns 0 (:441-443).
+ * tail_fwd: pts_loss [n] from ws_contrast_rows_fwd -> per_class [n_cls] (mean of the points with loss > 0 per label),
+ *   loss [1] = mean of the per_class entries > 0 (:498-504), w_cls [n_cls] = d loss / d pts_loss of a kept point of the class.
+ * tail_bwd: g [1] -> g_row [n] (the `g` operand of ws_contrast_rows_bwd).
+ * head_bwd: d_on [n,c] (modified in place: the slice rows' gradients d_xs [s,c] are added onto their points, duplicates in
+ *   slot order) -> d_x [n, c] (row stride ldd) through the backward of the normalisation.   c <= 16, s <= 2048, n_cls <= 16. */
+int64_t ws_contrast_head_scratch_bytes(int64_t n);
+int ws_contrast_head_fwd(const float* x, int64_t n, int32_t c, int64_t ldx, const int64_t* labels, float threshold,
+                         const float* u, const int64_t* r_given, int32_t s, float* on, float* inv_norm, uint8_t* certain,
+                         int64_t* lbl, int64_t* slc_idx, float* xs, int32_t* state, void* scratch, void* stream);
+int64_t ws_contrast_tail_scratch_bytes(int64_t n);
+int ws_contrast_tail_fwd(const float* pts_loss, const int64_t* lbl, int64_t n, int32_t n_cls, int32_t* state, float* per_class,
+                         float* w_cls, float* loss, void* scratch, void* stream);
+int ws_contrast_tail_bwd(const float* pts_loss, const int64_t* lbl, int64_t n, int32_t n_cls, const float* w_cls, const float* g,
+                         float* g_row, void* stream);
+int ws_contrast_head_bwd(float* d_on, const float* d_xs, const int64_t* slc_idx, int32_t s, const float* on,
+                         const float* inv_norm, int64_t n, int32_t c, float* d_x, int64_t ldd, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * bf16-feature path (BASELINE.json configs[4]: "deformable-KPConv ... bf16"; SURVEY.md section 8d C5:

@@ -79,3 +79,90 @@ def test_contrast_product_rejects_cpu_tensors():
 @pytest.mark.parametrize("case", CASES)
 def test_contrast_loss_gpu(case):
     _run(torch.device("cuda:0"), *case)
+
+
+def _both_forms(dev, outputs, labels, thd, slice_draw=None, seed=None):
+    """contrast_loss through the head / tail kernels and through the torch-op form: (loss, grad, slice) of each"""
+    from weasal_amd import architectures
+    cfg = wcfg.DALESPLConfig()
+    cfg.contrast_thd = thd
+    res = []
+    for kernels in (True, False):
+        architectures.CONTRAST_KERNELS = kernels
+        try:
+            if seed is not None:
+                torch.manual_seed(seed)
+                torch.cuda.manual_seed(seed)
+            net = KPFCNN.__new__(KPFCNN)
+            o = outputs.clone().to(dev).requires_grad_(True)
+            loss = KPFCNN.contrast_loss(net, o, labels.to(dev), cfg, slice_draw=slice_draw)
+            loss.backward()
+            res.append((float(loss.detach()), o.grad.cpu(), net.pts_loss.detach().cpu(),
+                        net.contrast_slice.cpu() if kernels else None))
+        finally:
+            architectures.CONTRAST_KERNELS = True
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_contrast_head_tail_kernels_match_torch_form(case):
+    """the fused head / tail (ws_contrast_head_* / _tail_*) against the same loss written with torch ops around
+    ops.contrast_rows: same slice, loss and logits gradient to fp32 rounding"""
+    seed, n, n_labeled, sharp, thd = case
+    dev = torch.device("cuda:0")
+    outputs, labels = _case(seed, n, n_labeled, sharp)
+    with torch.no_grad():
+        valid = int((((torch.softmax(outputs, 1).max(1)[0] > thd / 100) | (labels < 10))).sum())
+    g = torch.Generator().manual_seed(seed + 1)
+    draw = torch.zeros(0, dtype=torch.int64) if valid == 0 else \
+        torch.randint(0, valid, (1000 if valid >= 1000 else 1000 - valid,), generator=g)
+    (lk, gk, pk, slc), (lt, gt, pt, _) = _both_forms(dev, outputs, labels, thd, slice_draw=draw)
+    assert abs(lk - lt) <= 2e-6 * max(1.0, abs(lt)), (lk, lt)
+    assert float((pk - pt).abs().max()) <= 2e-6 * max(1.0, float(pt.abs().max()))
+    assert float((gk - gt).abs().max()) <= 2e-5 * max(float(gt.abs().max()), 1e-12)
+    if valid > 0:
+        # the slice: position r in the list of valid points
+        with torch.no_grad():
+            cert = ((torch.softmax(outputs, 1).max(1)[0] > thd / 100) | (labels < 10))
+            lst = torch.where(cert)[0]
+            r = draw if valid >= 1000 else torch.cat((torch.arange(valid), draw))
+        assert torch.equal(slc, lst[r])
+
+
+@pytest.mark.gpu
+def test_contrast_device_draw_full_size():
+    """400 000 points (DALES batch): the device-side draw from uniforms picks the same points as the prefix-sum formula
+    on the same uniforms, duplicates of a point in the slice included; loss and gradient agree with the torch-op form"""
+    dev = torch.device("cuda:0")
+    n = 400_000
+    outputs, labels = _case(11, n, 2000, 1.5)
+    (lk, gk, pk, slc), (lt, gt, pt, _) = _both_forms(dev, outputs, labels, 40, seed=123)
+    assert abs(lk - lt) <= 5e-6 * max(1.0, abs(lt)), (lk, lt)
+    assert float((gk - gt).abs().max()) <= 5e-5 * float(gt.abs().max())
+    # the draw itself, from the same generator state
+    torch.manual_seed(123)
+    torch.cuda.manual_seed(123)
+    u = torch.rand(1000, device=dev)
+    o = outputs.to(dev)
+    cert = (torch.softmax(o, 1).max(1)[0] > 0.4) | (labels.to(dev) < 10)
+    cs = torch.cumsum(cert.to(torch.int64), 0)
+    nv = cs[-1]
+    r = torch.minimum((u * nv.float()).floor().long(), nv - 1)
+    want = torch.searchsorted(cs, r + 1)
+    assert torch.equal(slc.to(dev), want)
+
+
+@pytest.mark.gpu
+def test_contrast_slice_duplicates_gradient():
+    """few valid points: the slice repeats points (:450-454); their gradients add up onto the same logits row"""
+    dev = torch.device("cuda:0")
+    outputs, labels = _case(21, 600, 12, 0.02)
+    with torch.no_grad():
+        valid = int((((torch.softmax(outputs, 1).max(1)[0] > 0.9) | (labels < 10))).sum())
+    assert 0 < valid < 50
+    draw = torch.randint(0, valid, (1000 - valid,), generator=torch.Generator().manual_seed(3))
+    (lk, gk, _, slc), (lt, gt, _, _) = _both_forms(dev, outputs, labels, 90, slice_draw=draw)
+    assert len(torch.unique(slc)) == valid
+    assert abs(lk - lt) <= 2e-6 * max(1.0, abs(lt))
+    assert float((gk - gt).abs().max()) <= 2e-5 * float(gt.abs().max())

@@ -41,6 +41,13 @@ SIGNATURES = {
     "ws_contrast_rows_bwd_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "ws_contrast_rows_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp]),
+    "ws_contrast_head_scratch_bytes": (_i64, [_i64]),
+    "ws_contrast_head_fwd": (C.c_int, [_vp, _i64, _i32, _i64, _vp, C.c_float, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp]),
+    "ws_contrast_tail_scratch_bytes": (_i64, [_i64]),
+    "ws_contrast_tail_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws_contrast_tail_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ws_contrast_head_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "ws_radius_neighbors_set_key_last": (C.c_int, [_vp, _vp]),
     "ws_radius_neighbors_reuse_grid": (C.c_int, [_vp, _i32]),
     "ws_radius_neighbors_grid_info": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

@@ -20,6 +20,7 @@ from .blocks import KPConv, NearestUpsampleBlock, UnaryBlock, block_decider, clo
 
 _LAYER_CHANGE = ('pool', 'strided', 'upsample', 'global')
 REGULARIZER_KERNEL = os.environ.get("WEASAL_REG_KERNEL", "1") != "0"      # A/B switch: 0 = the torch-op form below
+CONTRAST_KERNELS = os.environ.get("WEASAL_CONTRAST_KERNELS", "1") != "0"  # A/B switch: 0 = contrast_loss's head / tail as torch ops
 
 
 def p2p_fitting_regularizer(net):
@@ -225,6 +226,18 @@ class KPFCNN(nn.Module):
         threshold = config.contrast_thd / 100
         self.pts_loss = 0
         self.pts_loss_self = 0
+
+        if CONTRAST_KERNELS and outputs.is_cuda and outputs.dtype == torch.float32 and outputs.shape[1] <= 16:
+            # the whole loss as one node (ops.contrast_loss: 5 launches each way); the draw: slc_con device uniforms, or the
+            # explicit positions of the tests (fewer than slc_con of them = the "fewer valid points" branch, :450-454)
+            if slice_draw is None:
+                draw = torch.rand(slc_con, device=dev)
+            else:
+                slice_draw = slice_draw.to(dev).to(torch.int64)
+                nv_host = slc_con - slice_draw.shape[0]
+                draw = slice_draw if nv_host <= 0 else torch.cat((torch.arange(nv_host, device=dev), slice_draw), dim=0)
+            loss, self.pts_loss, self.contrast_slice, _ = ops.contrast_loss(outputs, labels, draw, threshold, temperature, eps)
+            return loss if base_temperature == 1 else loss / base_temperature
 
         prob = torch.softmax(outputs, 1)
         pseudo_logits = prob.max(1)[0]

@@ -1171,6 +1171,79 @@ def cross_entropy(logits, labels, lut=None, weight=None):
     return _SoftmaxCE.apply(logits, labels, lut, weight)
 
 
+class _ContrastLoss(torch.autograd.Function):
+    """the WHOLE of KPFCNN.contrast_loss (architectures.py:405-504) as one node: ws_contrast_head_fwd (softmax statistics,
+    pseudo labels, normalisation, device-side slice draw) -> ws_contrast_rows_fwd -> ws_contrast_tail_fwd; five launches
+    each way, no host synchronisation.  Returns (loss scalar, per_class [n_cls], slc_idx [s], num_valid int32 [1])."""
+
+    @staticmethod
+    def forward(ctx, x, labels, draw, threshold, temperature, eps, n_cls):
+        lib = _lib.lib()
+        x = x if (x.stride(1) == 1 and x.stride(0) >= x.shape[1]) else x.contiguous()
+        n, c = x.shape
+        dev = x.device
+        labels = labels.to(torch.int64).contiguous()
+        u = draw if draw.dtype == torch.float32 else None
+        r = draw if draw.dtype == torch.int64 else None
+        s = draw.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        on = torch.empty((n, c), **f32)
+        inv_norm, pts, rowmax, den, npos = (torch.empty((n,), **f32) for _ in range(5))
+        certain = torch.empty((n,), dtype=torch.uint8, device=dev)
+        lbl = torch.empty((n,), dtype=torch.int64, device=dev)
+        slc_idx = torch.empty((s,), dtype=torch.int64, device=dev)
+        xs = torch.empty((s, c), **f32)
+        state = torch.empty((2,), dtype=torch.int32, device=dev)
+        small = torch.empty((2 * n_cls + 1,), **f32)                 # per_class | w_cls | loss
+        scratch = torch.empty(max(lib.ws_contrast_head_scratch_bytes(n), lib.ws_contrast_tail_scratch_bytes(n)),
+                              dtype=torch.uint8, device=dev)
+        st = current_stream()
+        check(lib.ws_contrast_head_fwd(ptr(x), n, c, x.stride(0), ptr(labels), float(threshold), ptr(u), ptr(r), s, ptr(on),
+                                       ptr(inv_norm), ptr(certain), ptr(lbl), ptr(slc_idx), ptr(xs), ptr(state), ptr(scratch), st))
+        check(lib.ws_contrast_rows_fwd(ptr(on), n, c, ptr(xs), s, ptr(slc_idx), ptr(certain), ptr(lbl), float(temperature),
+                                       float(eps), ptr(pts), ptr(rowmax), ptr(den), ptr(npos), st))
+        per_class, w_cls, loss = small[:n_cls], small[n_cls:2 * n_cls], small[2 * n_cls]
+        check(lib.ws_contrast_tail_fwd(ptr(pts), ptr(lbl), n, n_cls, ptr(state), ptr(per_class), ptr(w_cls),
+                                       small.data_ptr() + 8 * n_cls, ptr(scratch), st))
+        ctx.save_for_backward(on, xs, slc_idx, certain, lbl, rowmax, den, npos, pts, inv_norm, small)
+        ctx.temperature, ctx.n_cls = float(temperature), n_cls
+        ctx.mark_non_differentiable(per_class, slc_idx, state)
+        return loss, per_class, slc_idx, state
+
+    @staticmethod
+    def backward(ctx, g, _g_pc, _g_idx, _g_state):
+        lib = _lib.lib()
+        on, xs, slc_idx, certain, lbl, rowmax, den, npos, pts, inv_norm, small = ctx.saved_tensors
+        n, c = on.shape
+        s = xs.shape[0]
+        n_cls = ctx.n_cls
+        st = current_stream()
+        g = g.to(torch.float32).contiguous()
+        g_row = torch.empty_like(pts)
+        check(lib.ws_contrast_tail_bwd(ptr(pts), ptr(lbl), n, n_cls, small.data_ptr() + 4 * n_cls, ptr(g), ptr(g_row), st))
+        d_on = torch.empty_like(on)
+        d_xs = torch.empty_like(xs)
+        scratch = torch.empty(max(lib.ws_contrast_rows_bwd_scratch_bytes(n, c, s), 16), dtype=torch.uint8, device=on.device)
+        check(lib.ws_contrast_rows_bwd(ptr(on), n, c, ptr(xs), s, ptr(slc_idx), ptr(certain), ptr(lbl), ctx.temperature,
+                                       ptr(rowmax), ptr(den), ptr(npos), ptr(g_row), ptr(d_on), ptr(d_xs), ptr(scratch), st))
+        d_x = torch.empty_like(on)
+        check(lib.ws_contrast_head_bwd(ptr(d_on), ptr(d_xs), ptr(slc_idx), s, ptr(on), ptr(inv_norm), n, c, ptr(d_x), c, st))
+        return d_x, None, None, None, None, None, None
+
+
+def contrast_loss(x, labels, draw, threshold, temperature=0.1, eps=1e-8, n_cls=None):
+    """KPFCNN.contrast_loss (architectures.py:405-504) on logits x [N, C] (C <= 16) and labels [N] (>= 10 = unlabelled).
+    `draw`: float32 [s] uniforms in [0, 1) (slot j takes valid point floor(u_j * num_valid)) or int64 [s] positions in the list
+    of valid points.  -> (loss, per_class [n_cls], slc_idx [s], state int32 [2] = (num_valid, 0))"""
+    _need_cuda(x, labels, draw)
+    if x.dim() != 2 or x.dtype != torch.float32 or x.shape[1] > 16:
+        raise _lib.WeasalHipError("contrast_loss takes float32 logits [N, C <= 16] (got %s %s)" % (x.dtype, tuple(x.shape)))
+    if draw.dtype not in (torch.float32, torch.int64) or draw.dim() != 1:
+        raise _lib.WeasalHipError("contrast_loss: draw must be float32 uniforms or int64 positions [s]")
+    n_cls = max(int(x.shape[1]), 10) if n_cls is None else int(n_cls)
+    return _ContrastLoss.apply(x, labels, draw.contiguous(), threshold, temperature, eps, n_cls)
+
+
 def contrast_rows(on, xs, slc_idx, certain, lbl, temperature, eps):
     """per-point supervised contrastive loss [N] (ws_contrast_rows_fwd / _bwd); on [N,C] normalised logits,
     xs [S,C] = on[slc_idx], certain [N] bool, lbl [N] pseudo labels"""

@@ -17,10 +17,13 @@ WORKLOADS = {
     "dales_deform_f32": dict(config="DALESDeformF32Config", radius=10.0, points=50000, spheres=8, limits=[422, 519, 472, 193, 34],
                              name="DALES deformable + modulated KP-FCNN in f32 rows (A/B of the bf16 path), "
                                   "in_radius=10m, 50k pts/sphere, batch=8"),
-    "vaihingen": dict(config="Vaihingen3DPLConfig", radius=4.0, points=3000, spheres=4, limits=[],
+    # limits of the two Vaihingen workloads: the reference's calibration rule (DALES_PseudoLabel.py:1186-1324: histograms cut
+    # at ceil(4/3 pi (deform_radius + 1)^3) columns, 90th percentile) over 24 un-limited batches of this distribution, run
+    # with the CPU oracle (the reference never runs without limits: its samplers calibrate them before the first epoch)
+    "vaihingen": dict(config="Vaihingen3DPLConfig", radius=4.0, points=3000, spheres=4, limits=[15, 50, 72, 52, 10],
                       name="Vaihingen3D_PseudoLabel KP-FCNN, in_radius=4m, 3k pts/sphere, batch=4"),
     # BASELINE config 1: the weak-label step of KPFCNN_mprm, 2 spheres of 3 000 points, R = 4 m
-    "vaihingen_wl": dict(config="Vaihingen3DWLConfig", radius=4.0, points=3000, spheres=2, limits=[],
+    "vaihingen_wl": dict(config="Vaihingen3DWLConfig", radius=4.0, points=3000, spheres=2, limits=[15, 32, 33],
                          name="Vaihingen3D_WeakLabel KPFCNN_mprm, in_radius=4m, 3k pts/sphere, batch=2"),
 }
 
