@@ -153,6 +153,17 @@ __device__ __forceinline__ void for_each_candidate(const CloudGrid& g, float qx,
     }
 }
 
+// The running maximum of the row lengths lives in ONE word: 16 384 waves each ending in an atomicMax on it serialise at
+// ~7.5 ns per atomic (measured: 0.9 ms per DALES pyramid, most of it exposed in the mid-size launches).  The maximum saturates
+// after a few hundred rows, so a wave first reads the word (a stale value is only ever too small) and skips the atomic
+// unless it would raise it.
+__device__ __forceinline__ void nb_publish_max(int32_t* __restrict__ max_count, int local_max, int lane)
+{
+    if (lane == 0 && local_max > 0 &&
+        local_max > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(max_count, local_max);
+}
+
 __device__ __forceinline__ int find_cloud_q(const CloudGrid* __restrict__ grids, int nb, int64_t q)
 {
     int b = 0;
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(256) void nb_count_kernel(const float* __restrict__
         if (lane == 0) counts[q] = cnt;
         local_max = max(local_max, cnt);
     }
-    if (lane == 0 && local_max > 0) atomicMax(max_count, local_max);
+    nb_publish_max(max_count, local_max, lane);
 }
 
 template <int CAP, typename OutT>
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(256) void nb_fill_kernel(const float* __restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (max_count && lane == 0 && local_max > 0) atomicMax(max_count, local_max);
+    if (max_count) nb_publish_max(max_count, local_max, lane);
 }
 
 // Fast path for rows of at most 128 neighbours (every layer of the KP-FCNN pyramids):
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (max_count && lane == 0 && local_max > 0) atomicMax(max_count, local_max);
+    if (max_count) nb_publish_max(max_count, local_max, lane);
 }
 
 // Rows of 129 .. 1024 neighbours: the deformable radius of BASELINE config 5 (datasets/common.py:500-502: every level is
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(256) void nb_fill_wide_kernel(const float* __restri
         if (key_last && cnt <= width && lane == 0) key_last[q] = ~0ull;
         wsync();
     }
-    if (max_count && lane == 0 && local_max > 0) atomicMax(max_count, local_max);
+    if (max_count) nb_publish_max(max_count, local_max, lane);
 }
 
 __global__ __launch_bounds__(256) void nb_order_kernel(const float4* __restrict__ sorted, int64_t ns, int32_t* __restrict__ order)
@@ -789,10 +800,14 @@ struct KeyLastGuard {
     ~KeyLastGuard() { if (ws) ws->key_last = nullptr; }
 };
 
+// lab switches (tools/k1_lab.py): grid cap and queries per workgroup of the fill launch
+extern "C" int ws_nb_max_blocks = 0;
+extern "C" int ws_nb_queries_per_block = 0;
+
 static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* out_i32, int64_t* out_i64,
                           bool with_counts, hipStream_t st)
 {
-    const int grid = ws_grid(ws->nq, 4);
+    const int grid = ws_grid(ws->nq, ws_nb_queries_per_block > 0 ? ws_nb_queries_per_block : 4, ws_nb_max_blocks > 0 ? ws_nb_max_blocks : 256 * 16);
     const int32_t* qo = ws->self_query ? ws->order.p : nullptr;
     int32_t* cn = with_counts ? ws->counts.p : nullptr;
     int32_t* mx = with_counts ? ws->max_count_word : nullptr;
