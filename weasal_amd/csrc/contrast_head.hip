@@ -78,6 +78,8 @@ __global__ __launch_bounds__(256) void contrast_prepare_kernel(const float* __re
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
+// grid = ceil(s / 64) workgroups of 16 waves; every workgroup rebuilds the (small) prefix of the block counts, then each
+// wave locates 4 slots: binary search over the prefix, then the block's `certain` bytes 256 at a time (4 per lane)
 __global__ __launch_bounds__(1024) void contrast_select_kernel(const int32_t* __restrict__ blk_cnt, int nblk, int rpb, int64_t n,
                                                                 const uint8_t* __restrict__ certain,
                                                                 const float* __restrict__ u, const int64_t* __restrict__ r_given,
@@ -110,8 +112,11 @@ __global__ __launch_bounds__(1024) void contrast_select_kernel(const int32_t* __
 #pragma unroll
     for (int k = 0; k < PER; ++k) pre[t * PER + k] = base + loc[k];
     __syncthreads();
-    if (t == 0) { state[0] = nv; state[1] = 0; }
-    for (int j = t; j < s; j += 1024) {
+    if (blockIdx.x == 0 && t == 0) { state[0] = nv; state[1] = 0; }
+    const int wave = t >> 6, lane = t & 63;
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = blockIdx.x * 64 + wave * 4 + jj;
+        if (j >= s) break;                                          // wave-uniform
         int64_t r;
         if (r_given) r = r_given[j];
         else {
@@ -131,11 +136,40 @@ __global__ __launch_bounds__(1024) void contrast_select_kernel(const int32_t* __
             int rem = (int)(r - pre[lo]);
             const int64_t a = (int64_t)lo * rpb;
             const int64_t bnd = a + rpb < n ? a + rpb : n;
-            for (int64_t p = a; p < bnd; ++p)
-                if (certain[p]) { if (rem == 0) { found = p; break; } --rem; }
+            for (int64_t p0 = a; p0 < bnd; p0 += 256) {
+                const int64_t p = p0 + 4 * lane;
+                unsigned bits = 0;                                  // bit k: row p + k is valid
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (p + k < bnd && certain[p + k]) bits |= 1u << k;
+                const int nz = __builtin_popcount(bits);
+                int incl = nz;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    incl += lane >= o ? v : 0;
+                }
+                const int total = __shfl(incl, 63, 64);
+                if (rem < total) {
+                    const int excl = incl - nz;
+                    const bool mine = rem >= excl && rem < incl;
+                    int64_t cand = 0;
+                    if (mine) {
+                        int need = rem - excl;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (bits & (1u << k)) { if (need == 0) cand = p + k; --need; }
+                    }
+                    const unsigned long long m = __ballot(mine);
+                    const int src = __builtin_ctzll(m);
+                    found = ((int64_t)__shfl((int)(cand >> 32), src, 64) << 32) | (unsigned)__shfl((int)(cand & 0xffffffffll), src, 64);
+                    break;
+                }
+                rem -= total;
+            }
         }
-        slc_idx[j] = found;
-        for (int k = 0; k < c; ++k) xs[(int64_t)j * c + k] = on[found * c + k];
+        if (lane == 0) slc_idx[j] = found;
+        if (lane < c) xs[(int64_t)j * c + lane] = on[found * c + lane];
     }
 }
 
@@ -177,12 +211,23 @@ __global__ __launch_bounds__(256) void contrast_tail_kernel(const float* __restr
     if (!last) return;
     __threadfence();
     __shared__ float pc[CH_BINS], sl[CH_BINS], cn[CH_BINS];
+    // the partials of all workgroups: fetched by all threads (independent loads), summed per class in block order
+    float* stage = &bs[0][0];                                       // CH_BINS x 257 floats, free again
+    float ssum = 0.0f, csum = 0.0f;
+    const int per_pass = (CH_BINS * 257) / (2 * CH_BINS);           // workgroups per pass through the staging area
+    for (unsigned b0 = 0; b0 < gridDim.x; b0 += per_pass) {
+        const unsigned nb_here = min((unsigned)per_pass, gridDim.x - b0);
+        __syncthreads();
+        for (unsigned e = t; e < nb_here * 2 * CH_BINS; e += 256)
+            stage[e] = __hip_atomic_load(&partial[(int64_t)b0 * 2 * CH_BINS + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (t < n_cls)
+            for (unsigned b = 0; b < nb_here; ++b) {
+                ssum += stage[(b * 2 + 0) * CH_BINS + t];
+                csum += stage[(b * 2 + 1) * CH_BINS + t];
+            }
+    }
     if (t < n_cls) {
-        float ssum = 0.0f, csum = 0.0f;
-        for (unsigned b = 0; b < gridDim.x; ++b) {
-            ssum += __hip_atomic_load(&partial[((int64_t)b * 2 + 0) * CH_BINS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            csum += __hip_atomic_load(&partial[((int64_t)b * 2 + 1) * CH_BINS + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         const float mean = ssum / fmaxf(csum, 1.0f);
         pc[t] = mean;
         sl[t] = mean > 0.0f ? 1.0f : 0.0f;
@@ -211,32 +256,36 @@ __global__ __launch_bounds__(256) void contrast_tail_bwd_kernel(const float* __r
     g_row[p] = pts_loss[p] > 0.0f ? g[0] * w_cls[k] : 0.0f;
 }
 
-// slice-row gradients back onto their points: the FIRST slot of a point adds all its slots in slot order (deterministic)
-__global__ __launch_bounds__(1024) void contrast_slice_add_kernel(const float* __restrict__ d_xs, const int64_t* __restrict__ slc_idx,
-                                                                   int s, int c, float* __restrict__ d_on)
+// slice-row gradients back onto their points: the FIRST slot of a point adds all its slots in slot order (deterministic).
+// 16 lanes per slot: they scan the slot table together (is there an earlier slot of the same point?  later ones?); later
+// duplicates are rare (about one per 1000 draws out of 400 000) and then added one after the other.
+__global__ __launch_bounds__(256) void contrast_slice_add_kernel(const float* __restrict__ d_xs, const int64_t* __restrict__ slc_idx,
+                                                                  int s, int c, float* __restrict__ d_on)
 {
     __shared__ int idx[2048];
-    for (int j = threadIdx.x; j < s; j += 1024) idx[j] = (int)slc_idx[j];
+    for (int j = threadIdx.x; j < s; j += 256) idx[j] = (int)slc_idx[j];
     __syncthreads();
-    for (int j = threadIdx.x; j < s; j += 1024) {
-        const int me = idx[j];
-        bool first = true;
-        for (int q = 0; q < j; ++q)
-            if (idx[q] == me) { first = false; break; }
-        if (!first) continue;
-        float a[CH_CMAX];
+    const int j = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const bool live = j < s;
+    const int me = live ? idx[j] : -1;
+    int before = 0, after = 0;
+    if (live)
+        for (int q = l; q < s; q += 16) {
+            const bool same = idx[q] == me;
+            before += (same && q < j) ? 1 : 0;
+            after += (same && q > j) ? 1 : 0;
+        }
 #pragma unroll
-        for (int k = 0; k < CH_CMAX; ++k) a[k] = k < c ? d_on[(int64_t)me * c + k] + d_xs[(int64_t)j * c + k] : 0.0f;
-        for (int q = j + 1; q < s; ++q)
-            if (idx[q] == me) {
-#pragma unroll
-                for (int k = 0; k < CH_CMAX; ++k)
-                    if (k < c) a[k] += d_xs[(int64_t)q * c + k];
-            }
-#pragma unroll
-        for (int k = 0; k < CH_CMAX; ++k)
-            if (k < c) d_on[(int64_t)me * c + k] = a[k];
+    for (int o = 8; o > 0; o >>= 1) {
+        before += __shfl_xor(before, o, 16);
+        after += __shfl_xor(after, o, 16);
     }
+    if (!live || before > 0 || l >= c) return;
+    float a = d_on[(int64_t)me * c + l] + d_xs[(int64_t)j * c + l];
+    if (after > 0)
+        for (int q = j + 1; q < s; ++q)
+            if (idx[q] == me) a += d_xs[(int64_t)q * c + l];
+    d_on[(int64_t)me * c + l] = a;
 }
 
 __global__ __launch_bounds__(256) void contrast_normalize_bwd_kernel(const float* __restrict__ d_on, const float* __restrict__ on,
@@ -292,7 +341,7 @@ int ws_contrast_head_fwd(const float* x, int64_t n, int32_t c, int64_t ldx, cons
     int32_t* blk_cnt = (int32_t*)scratch;
     contrast_prepare_kernel<<<nblk, 256, 0, st>>>(x, n, c, ldx, labels, threshold, rpb, on, inv_norm, certain, lbl, blk_cnt);
     WS_LAUNCH_CHECK();
-    contrast_select_kernel<<<1, 1024, 0, st>>>(blk_cnt, nblk, rpb, n, certain, u, r_given, s, on, c, slc_idx, xs, state);
+    contrast_select_kernel<<<(unsigned)ws_ceil_div(s, 64), 1024, 0, st>>>(blk_cnt, nblk, rpb, n, certain, u, r_given, s, on, c, slc_idx, xs, state);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
@@ -331,7 +380,7 @@ int ws_contrast_head_bwd(float* d_on, const float* d_xs, const int64_t* slc_idx,
     WS_REQUIRE(d_on && d_xs && slc_idx && on && inv_norm && d_x, "NULL argument");
     WS_REQUIRE(n >= 1 && c >= 1 && c <= CH_CMAX && s >= 1 && s <= 2048 && ldd >= c, "size out of range");
     hipStream_t st = (hipStream_t)stream;
-    contrast_slice_add_kernel<<<1, 1024, 0, st>>>(d_xs, slc_idx, s, c, d_on);
+    contrast_slice_add_kernel<<<(unsigned)ws_ceil_div(s, 16), 256, 0, st>>>(d_xs, slc_idx, s, c, d_on);
     WS_LAUNCH_CHECK();
     contrast_normalize_bwd_kernel<<<(unsigned)ws_ceil_div(n, 256), 256, 0, st>>>(d_on, on, inv_norm, n, c, d_x, ldd);
     WS_LAUNCH_CHECK();

@@ -221,19 +221,23 @@ __global__ __launch_bounds__(256) void contrast_bwd_mfma_kernel(const float* __r
         }
 }
 
-__global__ __launch_bounds__(256) void contrast_reduce2_kernel(const float* __restrict__ partial, int64_t elems, int chunks,
-                                                                float* __restrict__ out)
+__global__ __launch_bounds__(1024) void contrast_reduce2_kernel(const float* __restrict__ partial, int64_t elems, int chunks,
+                                                                 float* __restrict__ out)
 {
-    // element e of every chunk, 4 chunks in flight, fixed order; 64 elements x 4 chunk lanes per workgroup
-    __shared__ float red[4][64];
-    const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;
-    const int64_t e = (int64_t)blockIdx.x * 64 + el;
+    // 32 elements x 32 chunk lanes per workgroup: lane cl sums chunks cl, cl + 32, ... in order, then a fixed tree over cl
+    __shared__ float red[32][33];
+    const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + el;
     float sacc = 0.0f;
     if (e < elems)
-        for (int cidx = cl; cidx < chunks; cidx += 4) sacc += partial[(int64_t)cidx * elems + e];
+        for (int cidx = cl; cidx < chunks; cidx += 32) sacc += partial[(int64_t)cidx * elems + e];
     red[cl][el] = sacc;
     __syncthreads();
-    if (cl == 0 && e < elems) out[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    for (int o = 16; o > 0; o >>= 1) {
+        if (cl < o) red[cl][el] += red[cl + o][el];
+        __syncthreads();
+    }
+    if (cl == 0 && e < elems) out[e] = red[0][el];
 }
 
 }  // namespace
@@ -277,7 +281,7 @@ extern "C" int ws_contrast_mfma_bwd(const float* on, int64_t n, int32_t c, const
     WS_LAUNCH_CHECK();
     if (chunks > 1) {
         const int64_t elems = (int64_t)s * c;
-        contrast_reduce2_kernel<<<(unsigned)ws_ceil_div(elems, 64), 256, 0, st>>>(partial, elems, chunks, d_xs);
+        contrast_reduce2_kernel<<<(unsigned)ws_ceil_div(elems, 32), 1024, 0, st>>>(partial, elems, chunks, d_xs);
         WS_LAUNCH_CHECK();
     }
     return WS_OK;
