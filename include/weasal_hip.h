@@ -305,6 +305,51 @@ int ws_rotate_clouds_host(const float* points, int64_t n, const int32_t* h_lens,
                           const float* h_rot, int32_t transpose, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The whole input pyramid of one batch in ONE call: the per-layer loop of PointCloudDataset.segmentation_inputs
+ * (datasets/common.py:461-577) -- conv / pool / upsample searches and the grid subsampling with its random grid
+ * orientation (:77-135) for every level, matrices cropped to the neighbourhood limits (:336-346).  Same kernels and
+ * schedule as the per-call entries above (which it calls); the caller's interpreter stays released for the whole build.
+ * All outputs live in the caller's `arena` at the returned byte offsets (-1: not produced): points of level l >= 1
+ * (float [n[l],3]), neighbors (int64 [n[l], limit[l]]), pools (int64 [n[l+1], limit[l]]), upsamples (int64 [n[l],
+ * limit[l+1]]), the cell order of every searched level (int32 [n[l]]), with want_grids the exported search grid and
+ * key_last of the self-query searches (ws_radius_neighbors_grid_export / _set_key_last), the lengths (int32
+ * [n_levels][nb]) and 4 n_levels int32 slots (maximum row lengths; then n_levels zeroed flags for the grid backward).
+ * max_count [3 l + {0 conv, 1 pool, 2 upsample}] = true maximum row length of that search (host; -1: no such search):
+ * 0 = the reference's empty-result error, < width = the caller may trim, > 128 (1024 for limits > 128) = the row slab
+ * of the asynchronous search overflowed and the caller repeats that search with the two-call protocol.
+ * WS_ERR_CAPACITY: the arena is too small; needed_bytes is set, nothing else is valid.  Synchronises the stream.
+ * ------------------------------------------------------------------------------------------ */
+#define WS_PYRAMID_MAX_LEVELS 8
+#define WS_PYRAMID_MAX_BATCH 64
+typedef struct ws_pyramid_desc {
+    /* in */
+    int32_t n_levels, nb, want_grids, reserved0;
+    const float* points;                 /* level 0: [n0,3] device */
+    int64_t n0;
+    const float* h_rot;                  /* host [n_levels-1][nb][3][3] grid orientations (common.py:99-121) or NULL */
+    void* arena; int64_t arena_bytes;    /* device, 256-byte aligned */
+    void* scratch; int64_t scratch_bytes;/* device, >= 2 * align256(12 n0) */
+    int32_t conv_on[WS_PYRAMID_MAX_LEVELS], pool_on[WS_PYRAMID_MAX_LEVELS];
+    float r_conv[WS_PYRAMID_MAX_LEVELS], r_pool[WS_PYRAMID_MAX_LEVELS], r_up[WS_PYRAMID_MAX_LEVELS], dl[WS_PYRAMID_MAX_LEVELS];
+    int32_t limit[WS_PYRAMID_MAX_LEVELS + 1];
+    int32_t reserved1;
+    /* in (level 0) / out (levels >= 1) */
+    int32_t lens[WS_PYRAMID_MAX_LEVELS][WS_PYRAMID_MAX_BATCH];
+    /* out */
+    int64_t needed_bytes;
+    int64_t n[WS_PYRAMID_MAX_LEVELS];
+    int64_t off_points[WS_PYRAMID_MAX_LEVELS], off_neighbors[WS_PYRAMID_MAX_LEVELS], off_pools[WS_PYRAMID_MAX_LEVELS],
+            off_upsamples[WS_PYRAMID_MAX_LEVELS], off_order[WS_PYRAMID_MAX_LEVELS], off_key_last[WS_PYRAMID_MAX_LEVELS],
+            off_blob[WS_PYRAMID_MAX_LEVELS], blob_bytes[WS_PYRAMID_MAX_LEVELS], grid_cells[WS_PYRAMID_MAX_LEVELS];
+    int64_t off_lens, off_slots;
+    int32_t max_count[3 * WS_PYRAMID_MAX_LEVELS], width[3 * WS_PYRAMID_MAX_LEVELS];
+} ws_pyramid_desc;
+int ws_pyramid_build(ws_neighbors_ws* nws, ws_subsample_ws* sws, ws_pyramid_desc* desc, void* stream);
+int64_t ws_pyramid_desc_bytes(void);   /* sizeof(ws_pyramid_desc): lets a binding check its mirror of the struct */
+
+
+
+/* ------------------------------------------------------------------------------------------
  * Supervised contrastive loss of the pseudo-label trainer, the [N, slc_con] part of
  * KPFCNN.contrast_loss (models/architectures.py:455-497), fused: per point i
  *   loss[i] = -T * mean over the positive slice columns of log-softmax(<on_i, xs_j>/T over the usable columns)

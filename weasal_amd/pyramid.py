@@ -155,6 +155,191 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
             + [stacked_features, labels])
 
 
+# ------------------------------------------------------------------------------------------------
+# the same pyramid behind ONE library call (ws_pyramid_build, csrc/pyramid.hip)
+# ------------------------------------------------------------------------------------------------
+import ctypes as _C
+import os as _os
+import threading as _threading
+
+NATIVE_PYRAMID = _os.environ.get("WEASAL_NATIVE_PYRAMID", "1") != "0"     # A/B switch: 0 = the per-call loop above
+_ML, _MB = 8, 64          # WS_PYRAMID_MAX_LEVELS, WS_PYRAMID_MAX_BATCH
+
+
+class PyramidDesc(_C.Structure):
+    """mirror of `struct ws_pyramid_desc` (include/weasal_hip.h)"""
+    _fields_ = ([("n_levels", _C.c_int32), ("nb", _C.c_int32), ("want_grids", _C.c_int32), ("reserved0", _C.c_int32),
+                 ("points", _C.c_void_p), ("n0", _C.c_int64), ("h_rot", _C.c_void_p),
+                 ("arena", _C.c_void_p), ("arena_bytes", _C.c_int64), ("scratch", _C.c_void_p), ("scratch_bytes", _C.c_int64),
+                 ("conv_on", _C.c_int32 * _ML), ("pool_on", _C.c_int32 * _ML),
+                 ("r_conv", _C.c_float * _ML), ("r_pool", _C.c_float * _ML), ("r_up", _C.c_float * _ML), ("dl", _C.c_float * _ML),
+                 ("limit", _C.c_int32 * (_ML + 1)), ("reserved1", _C.c_int32),
+                 ("lens", (_C.c_int32 * _MB) * _ML),
+                 ("needed_bytes", _C.c_int64), ("n", _C.c_int64 * _ML)]
+                + [(name, _C.c_int64 * _ML) for name in ("off_points", "off_neighbors", "off_pools", "off_upsamples", "off_order",
+                                                          "off_key_last", "off_blob", "blob_bytes", "grid_cells")]
+                + [("off_lens", _C.c_int64), ("off_slots", _C.c_int64),
+                   ("max_count", _C.c_int32 * (3 * _ML)), ("width", _C.c_int32 * (3 * _ML))])
+
+
+_arena_hint = {}          # (device index, thread, n0, limits) -> bytes the previous batch of that shape needed
+
+
+def _schedule(config, limits):
+    """the per-level plan of segmentation_inputs as flat arrays: (conv_on, pool_on, r_conv, r_pool, r_up, dl) per level"""
+    r_normal = config.first_subsampling_dl * config.conv_radius
+    levels = []
+    layer_blocks = []
+    for block in config.architecture:
+        if not any(tag in block for tag in ('pool', 'strided', 'global', 'upsample')):
+            layer_blocks.append(block)
+            continue
+        lv = dict(conv_on=bool(layer_blocks), pool_on=False, r_conv=0.0, r_pool=0.0, r_up=0.0, dl=0.0)
+        if layer_blocks:
+            deform = any('deformable' in b for b in layer_blocks)
+            lv["r_conv"] = r_normal * config.deform_radius / config.conv_radius if deform else r_normal
+        if 'pool' in block or 'strided' in block:
+            lv["pool_on"] = True
+            lv["dl"] = 2 * r_normal / config.conv_radius
+            r = r_normal * config.deform_radius / config.conv_radius if 'deformable' in block else r_normal
+            lv["r_pool"], lv["r_up"] = r, 2 * r
+        levels.append(lv)
+        r_normal *= 2
+        layer_blocks = []
+        if 'global' in block or 'upsample' in block:
+            break
+    return levels
+
+
+def native_eligible(config, points, lens, limits):
+    return (NATIVE_PYRAMID and points.is_cuda and len(limits) > 0 and 1 <= len(lens) <= _MB
+            and len(_schedule(config, limits)) <= _ML)
+
+
+def segmentation_inputs_native(config, stacked_points, stacked_features, labels, stack_lengths, neighborhood_limits,
+                               random_grid_orient=True, point_orders=None, search_grids=None, rng=None, search_radii=None):
+    """segmentation_inputs for device tensors with neighbourhood limits, through ws_pyramid_build: same flat list, same
+    side lists (orders / grids / radii); every output is a view of one arena tensor."""
+    from . import _lib
+    lib = _lib.lib()
+    dev = stacked_points.device
+    P0 = stacked_points.detach().to(torch.float32).contiguous()
+    lens0 = np.asarray(stack_lengths.cpu() if isinstance(stack_lengths, torch.Tensor) else stack_lengths, dtype=np.int32)
+    levels = _schedule(config, neighborhood_limits)
+    L, B, n0 = len(levels), len(lens0), int(P0.shape[0])
+    limits = [int(v) for v in neighborhood_limits]
+    if len(limits) < L:
+        raise RuntimeError("neighborhood_limits has %d entries for %d layers" % (len(limits), L))
+    d = PyramidDesc()
+    d.n_levels, d.nb, d.want_grids = L, B, 1 if search_grids is not None else 0
+    d.points, d.n0 = P0.data_ptr(), n0
+    for l, lv in enumerate(levels):
+        d.conv_on[l], d.pool_on[l] = int(lv["conv_on"]), int(lv["pool_on"])
+        d.r_conv[l], d.r_pool[l], d.r_up[l], d.dl[l] = lv["r_conv"], lv["r_pool"], lv["r_up"], lv["dl"]
+        d.limit[l] = max(1, limits[l])
+    d.limit[L] = max(1, limits[L]) if len(limits) > L else 1
+    for b in range(B):
+        d.lens[0][b] = int(lens0[b])
+    rots = None
+    if random_grid_orient:
+        # the reference's draws, level by level (theta, phi, alpha per call: datasets/common.py:99-121)
+        rand = np.random.rand if rng is None else rng.rand
+        mats = []
+        for lv in levels:
+            if not lv["pool_on"]:
+                continue
+            theta = rand(B) * 2 * np.pi
+            phi = (rand(B) - 0.5) * np.pi
+            u = np.vstack([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
+            alpha = rand(B) * 2 * np.pi
+            mats.append(create_3D_rotations(u.T, alpha).astype(np.float32))
+        if mats:
+            rots = np.ascontiguousarray(np.stack(mats), dtype=np.float32)
+            d.h_rot = rots.ctypes.data
+    al = lambda v: (int(v) + 255) // 256 * 256
+    scratch = torch.empty(2 * al(n0 * 12) + 256, dtype=torch.uint8, device=dev)
+    d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
+    key = (dev.index or 0, _threading.get_ident(), n0, tuple(limits), L)
+    hint = _arena_hint.get(key)
+    if hint is None:
+        # first batch of this shape: guess that every level halves the point count (the subsampling cell doubles: usually
+        # a factor 4-6); a batch that needs more comes back with WS_ERR_CAPACITY and its exact size
+        hint = 1 << 20
+        for l in range(L):
+            nxt = limits[l + 1] if l + 1 < len(limits) else 0
+            hint += (n0 >> l) * ((2 * limits[l] + nxt) * 8 + 64) + 64 * B * 4
+    nws, sws = ops._ws.neighbors(dev), ops._ws.subsample(dev)
+    with torch.cuda.device(dev):
+        for attempt in range(3):
+            nbytes = (int(hint * 1.25) + (32 << 20) - 1) // (32 << 20) * (32 << 20)
+            arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            d.arena, d.arena_bytes = arena.data_ptr(), nbytes
+            rc = lib.ws_pyramid_build(nws, sws, _C.byref(d), _lib.current_stream())
+            if rc == 5 and d.needed_bytes > nbytes:            # WS_ERR_CAPACITY: the sizes are known now
+                hint = d.needed_bytes
+                arena = None
+                continue
+            _lib.check(rc)
+            break
+        else:
+            raise _lib.WeasalHipError("ws_pyramid_build: the arena stayed too small after three attempts")
+    _arena_hint[key] = int(d.needed_bytes)
+
+    def view(off, nbytes, dtype, shape):
+        return arena[off:off + nbytes].view(dtype).view(shape)
+
+    n = [int(d.n[l]) for l in range(L)]
+    points = [P0] + [view(d.off_points[l], n[l] * 12, torch.float32, (n[l], 3)) for l in range(1, L)]
+    lens_all = view(d.off_lens, L * B * 4, torch.int32, (L, B))
+    lens_host = [np.array(d.lens[l][:B], dtype=np.int32) for l in range(L)]
+    slots = view(d.off_slots, 4 * L * 4, torch.int32, (4 * L,))
+    empty_i = lambda: torch.zeros((0, 1), dtype=torch.int64, device=dev)
+    cap_of = lambda width: 1024 if width > 128 else 128
+
+    def finish(l, kind, off, rows, q, s, ql, sl, radius):
+        """the matrix of search (l, kind) as the reference's crop leaves it: trimmed to the true width when that is smaller
+        than the limit; redone with the two-call protocol in the rare case of a row beyond the asynchronous search's slab"""
+        width, mc = int(d.width[3 * l + kind]), int(d.max_count[3 * l + kind])
+        if mc == 0:
+            raise _lib.WeasalHipError("libweasal_hip status 4: Error")
+        mat = view(off, rows * width * 8, torch.int64, (rows, width))
+        if mc > cap_of(width):
+            mat = ops.radius_neighbors(q, s, ql, sl, radius, limit=width, dtype=torch.int64)
+        elif mc < width:
+            mat = mat[:, :mc].contiguous()
+        if search_radii is not None:
+            search_radii.append((mat, float(np.float32(radius))))
+        return mat, mc
+
+    neighbors, pools, upsamples = [], [], []
+    orders = [] if point_orders is None else point_orders
+    for l, lv in enumerate(levels):
+        if lv["conv_on"]:
+            mat, mc = finish(l, 0, d.off_neighbors[l], n[l], points[l], points[l], lens_host[l], lens_host[l], lv["r_conv"])
+            neighbors.append(mat)
+            orders.append((points[l], view(d.off_order[l], n[l] * 4, torch.int32, (n[l],))))
+            if search_grids is not None and 0 < mc <= cap_of(int(d.width[3 * l])):
+                grid = ops.SearchGrid()
+                grid.blob = view(d.off_blob[l], int(d.blob_bytes[l]), torch.uint8, (int(d.blob_bytes[l]),))
+                grid.nb, grid.cells, grid.ns = B, int(d.grid_cells[l]), n[l]
+                grid.key_last = view(d.off_key_last[l], n[l] * 8, torch.int64, (n[l],))
+                grid.radius = float(np.float32(lv["r_conv"]))
+                grid.overflow = slots[3 * L + l:3 * L + l + 1]
+                grid.max_count, grid.cap = mc, cap_of(int(d.width[3 * l]))
+                search_grids.append((mat, grid))
+        else:
+            neighbors.append(empty_i())
+        if lv["pool_on"]:
+            mat, _ = finish(l, 1, d.off_pools[l], n[l + 1], points[l + 1], points[l], lens_host[l + 1], lens_host[l], lv["r_pool"])
+            pools.append(mat)
+            mat, _ = finish(l, 2, d.off_upsamples[l], n[l], points[l], points[l + 1], lens_host[l], lens_host[l + 1], lv["r_up"])
+            upsamples.append(mat)
+        else:
+            pools.append(empty_i())
+            upsamples.append(empty_i())
+    return points + neighbors + pools + upsamples + [lens_all[l] for l in range(L)] + [stacked_features, labels]
+
+
 ACTIVATE_STALLS = None       # set to a list to collect (event, event) pairs around the hand-over wait (bench.py --stall-diag)
 
 
@@ -263,8 +448,10 @@ class PyramidBatch:
 def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True,
                 with_tables=True, rng=None):
     orders, grids, radii = [], [], []
-    li = segmentation_inputs(config, points, features, labels, lengths, neighborhood_limits, random_grid_orient,
-                             point_orders=orders, search_grids=grids if points.is_cuda else None, rng=rng, search_radii=radii)
+    lens_np = np.asarray(lengths.cpu() if isinstance(lengths, torch.Tensor) else lengths, dtype=np.int32)
+    build = segmentation_inputs_native if native_eligible(config, points, lens_np, neighborhood_limits) else segmentation_inputs
+    li = build(config, points, features, labels, lens_np, neighborhood_limits, random_grid_orient,
+               point_orders=orders, search_grids=grids if points.is_cuda else None, rng=rng, search_radii=radii)
     batch = PyramidBatch(li, orders)
     batch.search_grids = grids
     batch.search_radii = radii
