@@ -317,13 +317,17 @@ int ws_rotate_clouds_host(const float* points, int64_t n, const int32_t* h_lens,
  * max_count [3 l + {0 conv, 1 pool, 2 upsample}] = true maximum row length of that search (host; -1: no such search):
  * 0 = the reference's empty-result error, < width = the caller may trim, > 128 (1024 for limits > 128) = the row slab
  * of the asynchronous search overflowed and the caller repeats that search with the two-call protocol.
+ * Matrices whose widest row is shorter than the limit are cropped in place to that width (final_width; 0 = left to the
+ * caller: empty / overflowed).  want_tables: the transposed tables (ws_transpose_build) of the pooling matrices, of the
+ * first column of the upsampling matrices and -- without want_grids -- of the convolution matrices, at off_toffsets /
+ * off_tpairs [3 l + kind] (-1: none).  scratch must also hold the largest matrix and the largest table's scratch.
  * WS_ERR_CAPACITY: the arena is too small; needed_bytes is set, nothing else is valid.  Synchronises the stream.
  * ------------------------------------------------------------------------------------------ */
 #define WS_PYRAMID_MAX_LEVELS 8
 #define WS_PYRAMID_MAX_BATCH 64
 typedef struct ws_pyramid_desc {
     /* in */
-    int32_t n_levels, nb, want_grids, reserved0;
+    int32_t n_levels, nb, want_grids, want_tables;
     const float* points;                 /* level 0: [n0,3] device */
     int64_t n0;
     const float* h_rot;                  /* host [n_levels-1][nb][3][3] grid orientations (common.py:99-121) or NULL */
@@ -342,7 +346,9 @@ typedef struct ws_pyramid_desc {
             off_upsamples[WS_PYRAMID_MAX_LEVELS], off_order[WS_PYRAMID_MAX_LEVELS], off_key_last[WS_PYRAMID_MAX_LEVELS],
             off_blob[WS_PYRAMID_MAX_LEVELS], blob_bytes[WS_PYRAMID_MAX_LEVELS], grid_cells[WS_PYRAMID_MAX_LEVELS];
     int64_t off_lens, off_slots;
-    int32_t max_count[3 * WS_PYRAMID_MAX_LEVELS], width[3 * WS_PYRAMID_MAX_LEVELS];
+    int32_t max_count[3 * WS_PYRAMID_MAX_LEVELS], width[3 * WS_PYRAMID_MAX_LEVELS], final_width[3 * WS_PYRAMID_MAX_LEVELS];
+    int32_t reserved2[3 * WS_PYRAMID_MAX_LEVELS];
+    int64_t off_toffsets[3 * WS_PYRAMID_MAX_LEVELS], off_tpairs[3 * WS_PYRAMID_MAX_LEVELS];
 } ws_pyramid_desc;
 int ws_pyramid_build(ws_neighbors_ws* nws, ws_subsample_ws* sws, ws_pyramid_desc* desc, void* stream);
 int64_t ws_pyramid_desc_bytes(void);   /* sizeof(ws_pyramid_desc): lets a binding check its mirror of the struct */

@@ -15,6 +15,7 @@
 #include "ws_common.h"
 #include "ws_grid.h"
 #include <string.h>
+#include <algorithm>
 
 namespace {
 
@@ -24,6 +25,15 @@ struct Bump {
     char* base; int64_t cap, used;
     int64_t take(int64_t bytes) { const int64_t o = used; used += al256(bytes > 0 ? bytes : 1); return o; }
 };
+
+// rows cropped to the true maximum width (what the reference's crop yields when no row reaches the limit): packed copy
+__global__ __launch_bounds__(256) void pyr_trim_kernel(const int64_t* __restrict__ src, int64_t rows, int w, int mc,
+                                                        int64_t* __restrict__ dst)
+{
+    const int64_t total = rows * (int64_t)mc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        dst[i] = src[(i / mc) * w + (i % mc)];
+}
 
 }  // namespace
 
@@ -41,6 +51,7 @@ extern "C" int ws_pyramid_build(ws_neighbors_ws* nws, ws_subsample_ws* sws, ws_p
     for (int b = 0; b < nb; ++b) { WS_REQUIRE(d->lens[0][b] >= 0, "negative batch length"); sum0 += d->lens[0][b]; }
     WS_REQUIRE(sum0 == d->n0, "batch lengths do not sum to the point count");
     WS_REQUIRE(d->scratch_bytes >= 2 * al256(d->n0 * 12), "scratch too small: 2 x n0 x 12 bytes (256-byte aligned) needed");
+    WS_REQUIRE(((uintptr_t)d->scratch & 255) == 0 && ((uintptr_t)d->arena & 255) == 0, "arena / scratch must be 256-byte aligned");
     for (int l = 0; l < L; ++l) {
         WS_REQUIRE(d->limit[l] >= 1, "neighbourhood limits must be given (>= 1) for every level");
         if (d->pool_on[l]) WS_REQUIRE(l + 1 < L && d->limit[l + 1] >= 1 && d->dl[l] > 0.0f, "a pooling level needs a next level");
@@ -111,6 +122,31 @@ extern "C" int ws_pyramid_build(ws_neighbors_ws* nws, ws_subsample_ws* sws, ws_p
         d->off_pools[l] = d->pool_on[l] ? A.take(d->n[l + 1] * d->limit[l] * 8) : -1;
         d->off_upsamples[l] = d->pool_on[l] ? A.take(n * d->limit[l + 1] * 8) : -1;
     }
+    for (int l = 0; l < L; ++l)
+        for (int k = 0; k < 3; ++k) { d->off_toffsets[3 * l + k] = -1; d->off_tpairs[3 * l + k] = -1; d->final_width[3 * l + k] = 0; }
+    int64_t trim_bytes = 0, tr_bytes = 0;          // scratch the post-processing needs
+    for (int l = 0; l < L; ++l) {
+        const int64_t n = d->n[l];
+        if (d->conv_on[l]) trim_bytes = std::max(trim_bytes, n * d->limit[l] * 8);
+        if (d->pool_on[l]) trim_bytes = std::max(trim_bytes, std::max(d->n[l + 1] * d->limit[l] * 8, n * d->limit[l + 1] * 8));
+        if (!d->want_tables) continue;
+        if (d->conv_on[l] && !d->want_grids) {     // (with grids the self-query layers need no table; a rare fallback builds it lazily)
+            d->off_toffsets[3 * l] = A.take((n + 2) * 4);
+            d->off_tpairs[3 * l] = A.take(n * d->limit[l] * 4);
+            tr_bytes = std::max(tr_bytes, ws_transpose_scratch_bytes(n, d->limit[l], n));
+        }
+        if (d->pool_on[l]) {
+            const int64_t m = d->n[l + 1];
+            d->off_toffsets[3 * l + 1] = A.take((n + 2) * 4);
+            d->off_tpairs[3 * l + 1] = A.take(m * d->limit[l] * 4);
+            tr_bytes = std::max(tr_bytes, ws_transpose_scratch_bytes(m, d->limit[l], n));
+            d->off_toffsets[3 * l + 2] = A.take((m + 2) * 4);                  // first column of the upsampling matrix
+            d->off_tpairs[3 * l + 2] = A.take(n * 4);
+            tr_bytes = std::max(tr_bytes, al256(n * 8) + ws_transpose_scratch_bytes(n, 1, m));
+        }
+    }
+    WS_REQUIRE(d->scratch_bytes >= std::max(trim_bytes, tr_bytes), "scratch too small: %lld bytes needed for the cropped copies / tables",
+               (long long)std::max(trim_bytes, tr_bytes));
     d->off_lens = A.take((int64_t)L * nb * 4);
     d->off_slots = A.take((int64_t)(3 * L + L) * 4);                       // max-count slots, then one overflow flag per level
     d->needed_bytes = A.used;
@@ -167,5 +203,50 @@ extern "C" int ws_pyramid_build(ws_neighbors_ws* nws, ws_subsample_ws* sws, ws_p
     for (int l = 0; l < L; ++l)
         for (int k = 0; k < 3; ++k)
             if (d->width[3 * l + k] > 0) d->max_count[3 * l + k] = host_slots[3 * l + k];
+    // ---- the crop to the true width (datasets/common.py:336-346 crops to min(limit, widest row)), then the transposed
+    //      tables of the pooling / upsampling matrices (every backward of the batch needs them; built on this stream)
+    for (int l = 0; l < L; ++l)
+        for (int k = 0; k < 3; ++k) {
+            const int w = d->width[3 * l + k], mc = d->max_count[3 * l + k];
+            if (w <= 0) continue;
+            const int cap = w > 128 ? 1024 : 128;
+            if (mc <= 0 || mc > cap) continue;                       // empty result / slab overflow: the caller's business
+            d->final_width[3 * l + k] = w;
+            if (mc < w) {
+                const int64_t rows = k == 1 ? d->n[l + 1] : d->n[l];
+                int64_t* mat = (int64_t*)(A.base + (k == 0 ? d->off_neighbors[l] : (k == 1 ? d->off_pools[l] : d->off_upsamples[l])));
+                pyr_trim_kernel<<<ws_grid(rows * mc, 256), 256, 0, st>>>(mat, rows, w, mc, (int64_t*)d->scratch);
+                WS_LAUNCH_CHECK();
+                WS_HIP(hipMemcpyAsync(mat, d->scratch, (size_t)(rows * mc) * 8, hipMemcpyDeviceToDevice, st));
+                d->final_width[3 * l + k] = mc;
+            }
+        }
+    if (d->want_tables)
+        for (int l = 0; l < L; ++l) {
+            const int64_t n = d->n[l];
+            if (d->off_toffsets[3 * l] >= 0 && d->final_width[3 * l] > 0) {
+                if ((rc = ws_transpose_build((const int64_t*)(A.base + d->off_neighbors[l]), n, d->final_width[3 * l], n,
+                                             (int32_t*)(A.base + d->off_toffsets[3 * l]), (int32_t*)(A.base + d->off_tpairs[3 * l]),
+                                             d->scratch, st)))
+                    return rc;
+            } else d->off_toffsets[3 * l] = -1;
+            if (!d->pool_on[l]) continue;
+            const int64_t m = d->n[l + 1];
+            if (d->final_width[3 * l + 1] > 0) {
+                if ((rc = ws_transpose_build((const int64_t*)(A.base + d->off_pools[l]), m, d->final_width[3 * l + 1], n,
+                                             (int32_t*)(A.base + d->off_toffsets[3 * l + 1]), (int32_t*)(A.base + d->off_tpairs[3 * l + 1]),
+                                             d->scratch, st)))
+                    return rc;
+            } else d->off_toffsets[3 * l + 1] = -1;
+            if (d->final_width[3 * l + 2] > 0) {
+                int64_t* col = (int64_t*)d->scratch;
+                pyr_trim_kernel<<<ws_grid(n, 256), 256, 0, st>>>((const int64_t*)(A.base + d->off_upsamples[l]), n,
+                                                                 d->final_width[3 * l + 2], 1, col);
+                WS_LAUNCH_CHECK();
+                if ((rc = ws_transpose_build(col, n, 1, m, (int32_t*)(A.base + d->off_toffsets[3 * l + 2]),
+                                             (int32_t*)(A.base + d->off_tpairs[3 * l + 2]), (char*)d->scratch + al256(n * 8), st)))
+                    return rc;
+            } else d->off_toffsets[3 * l + 2] = -1;
+        }
     return WS_OK;
 }

@@ -69,6 +69,14 @@ class TransposedTable:
                                      current_stream()))
 
 
+    @classmethod
+    def from_parts(cls, offsets, pairs, nq, h, ns):
+        """a table somebody else built (ws_pyramid_build): offsets int32 [ns + 2], pairs int32 [nq * h]"""
+        t = cls.__new__(cls)
+        t.offsets, t.pairs, t.nq, t.h, t.ns = offsets, pairs, int(nq), int(h), int(ns)
+        return t
+
+
 _tables = collections.OrderedDict()
 _TABLES_MAX = 32
 

@@ -168,7 +168,7 @@ _ML, _MB = 8, 64          # WS_PYRAMID_MAX_LEVELS, WS_PYRAMID_MAX_BATCH
 
 class PyramidDesc(_C.Structure):
     """mirror of `struct ws_pyramid_desc` (include/weasal_hip.h)"""
-    _fields_ = ([("n_levels", _C.c_int32), ("nb", _C.c_int32), ("want_grids", _C.c_int32), ("reserved0", _C.c_int32),
+    _fields_ = ([("n_levels", _C.c_int32), ("nb", _C.c_int32), ("want_grids", _C.c_int32), ("want_tables", _C.c_int32),
                  ("points", _C.c_void_p), ("n0", _C.c_int64), ("h_rot", _C.c_void_p),
                  ("arena", _C.c_void_p), ("arena_bytes", _C.c_int64), ("scratch", _C.c_void_p), ("scratch_bytes", _C.c_int64),
                  ("conv_on", _C.c_int32 * _ML), ("pool_on", _C.c_int32 * _ML),
@@ -179,7 +179,9 @@ class PyramidDesc(_C.Structure):
                 + [(name, _C.c_int64 * _ML) for name in ("off_points", "off_neighbors", "off_pools", "off_upsamples", "off_order",
                                                           "off_key_last", "off_blob", "blob_bytes", "grid_cells")]
                 + [("off_lens", _C.c_int64), ("off_slots", _C.c_int64),
-                   ("max_count", _C.c_int32 * (3 * _ML)), ("width", _C.c_int32 * (3 * _ML))])
+                   ("max_count", _C.c_int32 * (3 * _ML)), ("width", _C.c_int32 * (3 * _ML)),
+                   ("final_width", _C.c_int32 * (3 * _ML)), ("reserved2", _C.c_int32 * (3 * _ML)),
+                   ("off_toffsets", _C.c_int64 * (3 * _ML)), ("off_tpairs", _C.c_int64 * (3 * _ML))])
 
 
 _arena_hint = {}          # (device index, thread, n0, limits) -> bytes the previous batch of that shape needed
@@ -217,9 +219,11 @@ def native_eligible(config, points, lens, limits):
 
 
 def segmentation_inputs_native(config, stacked_points, stacked_features, labels, stack_lengths, neighborhood_limits,
-                               random_grid_orient=True, point_orders=None, search_grids=None, rng=None, search_radii=None):
+                               random_grid_orient=True, point_orders=None, search_grids=None, rng=None, search_radii=None,
+                               tables=None):
     """segmentation_inputs for device tensors with neighbourhood limits, through ws_pyramid_build: same flat list, same
-    side lists (orders / grids / radii); every output is a view of one arena tensor."""
+    side lists (orders / grids / radii); every output is a view of one arena tensor.  `tables`: a dict that receives the
+    pre-built transposed tables {"full": [(matrix, ns, table)], "col0": [(upsampling matrix, nc, table)]}."""
     from . import _lib
     lib = _lib.lib()
     dev = stacked_points.device
@@ -231,7 +235,8 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
     if len(limits) < L:
         raise RuntimeError("neighborhood_limits has %d entries for %d layers" % (len(limits), L))
     d = PyramidDesc()
-    d.n_levels, d.nb, d.want_grids = L, B, 1 if search_grids is not None else 0
+    d.n_levels, d.nb, d.want_grids = L, B, 1 if (search_grids is not None and ops.GRID_BACKWARD) else 0
+    d.want_tables = 1 if tables is not None else 0
     d.points, d.n0 = P0.data_ptr(), n0
     for l, lv in enumerate(levels):
         d.conv_on[l], d.pool_on[l] = int(lv["conv_on"]), int(lv["pool_on"])
@@ -257,7 +262,8 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
             rots = np.ascontiguousarray(np.stack(mats), dtype=np.float32)
             d.h_rot = rots.ctypes.data
     al = lambda v: (int(v) + 255) // 256 * 256
-    scratch = torch.empty(2 * al(n0 * 12) + 256, dtype=torch.uint8, device=dev)
+    # temporaries: two point buffers; the largest matrix (cropped copy) / the largest table's scratch (both <= n0 * widest row)
+    scratch = torch.empty(2 * al(n0 * 12) + n0 * max(limits[:L + 1]) * 8 + al(n0 * 8) + (1 << 20), dtype=torch.uint8, device=dev)
     d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
     key = (dev.index or 0, _threading.get_ident(), n0, tuple(limits), L)
     hint = _arena_hint.get(key)
@@ -299,14 +305,13 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
     def finish(l, kind, off, rows, q, s, ql, sl, radius):
         """the matrix of search (l, kind) as the reference's crop leaves it: trimmed to the true width when that is smaller
         than the limit; redone with the two-call protocol in the rare case of a row beyond the asynchronous search's slab"""
-        width, mc = int(d.width[3 * l + kind]), int(d.max_count[3 * l + kind])
+        width, mc, fw = int(d.width[3 * l + kind]), int(d.max_count[3 * l + kind]), int(d.final_width[3 * l + kind])
         if mc == 0:
             raise _lib.WeasalHipError("libweasal_hip status 4: Error")
-        mat = view(off, rows * width * 8, torch.int64, (rows, width))
-        if mc > cap_of(width):
+        if fw > 0:                                     # cropped in place to the widest row where that is below the limit
+            mat = view(off, rows * fw * 8, torch.int64, (rows, fw))
+        else:                                          # a row beyond the asynchronous search's slab
             mat = ops.radius_neighbors(q, s, ql, sl, radius, limit=width, dtype=torch.int64)
-        elif mc < width:
-            mat = mat[:, :mc].contiguous()
         if search_radii is not None:
             search_radii.append((mat, float(np.float32(radius))))
         return mat, mc
@@ -318,7 +323,7 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
             mat, mc = finish(l, 0, d.off_neighbors[l], n[l], points[l], points[l], lens_host[l], lens_host[l], lv["r_conv"])
             neighbors.append(mat)
             orders.append((points[l], view(d.off_order[l], n[l] * 4, torch.int32, (n[l],))))
-            if search_grids is not None and 0 < mc <= cap_of(int(d.width[3 * l])):
+            if d.want_grids and int(d.final_width[3 * l]) > 0:
                 grid = ops.SearchGrid()
                 grid.blob = view(d.off_blob[l], int(d.blob_bytes[l]), torch.uint8, (int(d.blob_bytes[l]),))
                 grid.nb, grid.cells, grid.ns = B, int(d.grid_cells[l]), n[l]
@@ -337,6 +342,31 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
         else:
             pools.append(empty_i())
             upsamples.append(empty_i())
+    if tables is not None:
+        full, col0 = [], []
+
+        def table(l, kind, nq, h, ns):
+            o = int(d.off_toffsets[3 * l + kind])
+            if o < 0:
+                return None
+            return ops.TransposedTable.from_parts(view(o, (ns + 2) * 4, torch.int32, (ns + 2,)),
+                                                  view(int(d.off_tpairs[3 * l + kind]), max(nq * h, 1) * 4, torch.int32, (max(nq * h, 1),)),
+                                                  nq, h, ns)
+        for l, lv in enumerate(levels):
+            if lv["conv_on"] and int(d.final_width[3 * l]) > 0:
+                tb = table(l, 0, n[l], int(d.final_width[3 * l]), n[l])
+                if tb is not None:
+                    full.append((neighbors[l], n[l], tb))
+            if lv["pool_on"]:
+                if int(d.final_width[3 * l + 1]) > 0:
+                    tb = table(l, 1, n[l + 1], int(d.final_width[3 * l + 1]), n[l])
+                    if tb is not None:
+                        full.append((pools[l], n[l], tb))
+                if int(d.final_width[3 * l + 2]) > 0:
+                    tb = table(l, 2, n[l], 1, n[l + 1])
+                    if tb is not None:
+                        col0.append((upsamples[l], n[l + 1], tb))
+        tables["full"], tables["col0"] = full, col0
     return points + neighbors + pools + upsamples + [lens_all[l] for l in range(L)] + [stacked_features, labels]
 
 
@@ -449,13 +479,20 @@ def build_batch(config, points, features, labels, lengths, neighborhood_limits=(
                 with_tables=True, rng=None):
     orders, grids, radii = [], [], []
     lens_np = np.asarray(lengths.cpu() if isinstance(lengths, torch.Tensor) else lengths, dtype=np.int32)
-    build = segmentation_inputs_native if native_eligible(config, points, lens_np, neighborhood_limits) else segmentation_inputs
-    li = build(config, points, features, labels, lens_np, neighborhood_limits, random_grid_orient,
-               point_orders=orders, search_grids=grids if points.is_cuda else None, rng=rng, search_radii=radii)
+    native = native_eligible(config, points, lens_np, neighborhood_limits)
+    tables = {} if (native and with_tables) else None
+    if native:
+        li = segmentation_inputs_native(config, points, features, labels, lens_np, neighborhood_limits, random_grid_orient,
+                                        point_orders=orders, search_grids=grids, rng=rng, search_radii=radii, tables=tables)
+    else:
+        li = segmentation_inputs(config, points, features, labels, lens_np, neighborhood_limits, random_grid_orient,
+                                 point_orders=orders, search_grids=grids if points.is_cuda else None, rng=rng, search_radii=radii)
     batch = PyramidBatch(li, orders)
     batch.search_grids = grids
     batch.search_radii = radii
-    if with_tables and points.is_cuda:
+    if tables is not None:
+        batch.tables, batch.col0_tables = tables["full"], tables["col0"]
+    elif with_tables and points.is_cuda:
         batch.build_tables()
     if points.is_cuda:
         batch.ready = torch.cuda.Event()
