@@ -364,6 +364,8 @@ def main():
     # HIP events around the K3 launches inside the block calls (launch stream); WEASAL_TIMED_MIN_ROWS: only layers with at
     # least that many query rows (A/B of the events' own cost)
     fused.set_timed(True, int(os.environ.get("WEASAL_TIMED_MIN_ROWS", "0")))
+    from weasal_amd import _lib as _wlib
+    launches0 = int(_wlib.lib().ws_launch_count())
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -372,6 +374,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    launches = int(_wlib.lib().ws_launch_count()) - launches0      # (the prefetch threads run ahead by up to `depth` batches: +- a pyramid)
     limiter.finish()                 # the K4G capacity flags of the last steps (outside the timed region: everything has completed)
     timer.enabled = False
     fused.set_timed(False)
@@ -415,6 +418,9 @@ def main():
                           "dist_world_size": dist.get_world_size() if world > 1 else 1,
                           "allreduce_bytes": sync.nbytes() if sync is not None else 0,
                           "allreduce_ms": sync.mean_ms() if sync is not None else None,
+                          # kernels this library launched per step, both streams (framework kernels -- dropout, the random draw of
+                          # the contrastive slice, autograd's gradient sums -- are not counted: ~15 per step)
+                          "library_launches_per_step": round(launches / args.steps, 1),
                           "host_threads_per_rank": "1 training + %d pyramid prefetch" % (prefetcher.workers if prefetcher is not None else 0),
                           "final_loss": float(loss.item())}}
         # ---- roofline of the fused KPConv gather kernel (K3) on the largest layer: HIP events on the launch stream,

@@ -33,7 +33,9 @@ typedef enum {
 enum { WS_INFLUENCE_LINEAR = 0, WS_INFLUENCE_CONSTANT = 1, WS_INFLUENCE_GAUSSIAN = 2 };
 enum { WS_AGGREGATION_SUM = 0, WS_AGGREGATION_CLOSEST = 1 };
 
-const char* ws_last_error(void);   /* thread-local message of the last failing call */
+const char* ws_last_error(void);
+/* kernels launched by this library since it was loaded (all threads, all streams): launches-per-step accounting */
+int64_t ws_launch_count(void);   /* thread-local message of the last failing call */
 const char* ws_version(void);
 int ws_device_count(void);         /* number of HIP devices visible (no context is created) */
 

@@ -607,6 +607,22 @@ __global__ __launch_bounds__(256) void nb_fill_wide_kernel(const float* __restri
     if (max_count) nb_publish_max(max_count, local_max, lane);
 }
 
+// one thread per cell: insertion sort of the cell's entries by support index (cells hold ~2-3 points; a few dozen at most)
+__global__ __launch_bounds__(256) void nb_cell_sort_kernel(const int32_t* __restrict__ cell_start, int64_t cells,
+                                                            float4* __restrict__ sorted)
+{
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cells; c += (int64_t)gridDim.x * 256) {
+        const int beg = cell_start[c], end = cell_start[c + 1];
+        for (int i = beg + 1; i < end; ++i) {
+            const float4 v = sorted[i];
+            const int key = __float_as_int(v.w);
+            int j = i - 1;
+            while (j >= beg && __float_as_int(sorted[j].w) > key) { sorted[j + 1] = sorted[j]; --j; }
+            sorted[j + 1] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nb_order_kernel(const float4* __restrict__ sorted, int64_t ns, int32_t* __restrict__ order)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ns; i += (int64_t)gridDim.x * 256)
@@ -762,6 +778,11 @@ static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, con
     if ((rc = ws_exclusive_scan_i32(ws->cell_start.p, ws->cell_start.p, cells, ws->scan_scratch.p, st))) return rc;
     WS_HIP(hipMemcpyAsync(ws->cursor.p, ws->cell_start.p, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToDevice, st));
     nb_bin_fill_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(supports, ns, ws->cell_of.p, ws->cursor.p, ws->sorted.p);
+    WS_LAUNCH_CHECK();
+    // the bin fill hands out slots inside a cell through an atomic cursor (arrival order); sorting every cell's few entries
+    // by index makes the cell-sorted copy -- and with it the cell order and the summation order of the grid-walk backward
+    // (ws_kpconv_gather_bwd_x_grid) -- a pure function of the input: bit-identical gradients from run to run
+    nb_cell_sort_kernel<<<ws_grid(cells, 256), 256, 0, st>>>(ws->cell_start.p, cells, ws->sorted.p);
     WS_LAUNCH_CHECK();
     nb_order_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(ws->sorted.p, ns, ws->order.p);
     WS_LAUNCH_CHECK();

@@ -711,6 +711,8 @@ int ws_rotate_clouds_host(const float* points, int64_t n, const int32_t* h_lens,
 }
 
 const char* ws_last_error(void) { return ws_errbuf(); }
+long long ws_launch_counter = 0;
+int64_t ws_launch_count(void) { return (int64_t)__atomic_load_n(&ws_launch_counter, __ATOMIC_RELAXED); }
 const char* ws_version(void) { return "weasal_hip 0.1 (gfx950)"; }
 int ws_device_count(void)
 {

@@ -32,7 +32,13 @@ inline int ws_fail(int code, const char* fmt, ...)
         if (!(cond)) return ws_fail(WS_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
-#define WS_LAUNCH_CHECK() WS_HIP(hipGetLastError())
+// every kernel launch of the library is followed by this check: it also counts them (ws_launch_count: bench.py's launches/step)
+extern "C" long long ws_launch_counter;
+#define WS_LAUNCH_CHECK()                         \
+    do {                                          \
+        __atomic_fetch_add(&ws_launch_counter, 1ll, __ATOMIC_RELAXED); \
+        WS_HIP(hipGetLastError());                \
+    } while (0)
 
 static inline int64_t ws_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
