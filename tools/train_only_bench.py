@@ -16,7 +16,8 @@ batches = []
 for s in range(3):
     pts, feats, labels, lens = synthetic.make_inputs(s, wl['spheres'], wl['points'], wl['radius'], cfg.in_features_dim)
     batches.append(pyramid.build_batch(cfg, torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev), lens, wl['limits']))
-for i in range(6): train_step(net, opt, batches[i % 3], cfg)
+EP = 0 if (len(sys.argv) > 2 and sys.argv[2] == 'contrast') else None
+for i in range(6): train_step(net, opt, batches[i % 3], cfg, epoch=EP)
 freeze_gc()
 torch.cuda.synchronize()
 lim = InFlightLimiter(4)
@@ -24,7 +25,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 t0 = time.perf_counter()
 wait = 0.0
 for i in range(steps):
-    train_step(net, opt, batches[i % 3], cfg)
+    train_step(net, opt, batches[i % 3], cfg, epoch=EP)
     tw = time.perf_counter()
     lim.tick()
     wait += time.perf_counter() - tw
