@@ -607,19 +607,21 @@ __global__ __launch_bounds__(256) void nb_fill_wide_kernel(const float* __restri
     if (max_count) nb_publish_max(max_count, local_max, lane);
 }
 
-// one thread per cell: insertion sort of the cell's entries by support index (cells hold ~2-3 points; a few dozen at most)
-__global__ __launch_bounds__(256) void nb_cell_sort_kernel(const int32_t* __restrict__ cell_start, int64_t cells,
-                                                            float4* __restrict__ sorted)
+// The bin fill hands out slots inside a cell through an atomic cursor (arrival order).  One thread per entry: its place
+// among the entries of its cell by support index (rank by counting over the cell's few entries), written to the final copy.
+// The cell-sorted copy, the cell order and the summation order of the grid-walk backward then are functions of the input alone.
+__global__ __launch_bounds__(256) void nb_cell_rank_kernel(const float4* __restrict__ arrived, int64_t ns,
+                                                            const int32_t* __restrict__ cell_of,
+                                                            const int32_t* __restrict__ cell_start, float4* __restrict__ sorted)
 {
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cells; c += (int64_t)gridDim.x * 256) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < ns; p += (int64_t)gridDim.x * 256) {
+        const float4 v = arrived[p];
+        const int idx = __float_as_int(v.w);
+        const int c = cell_of[idx];
         const int beg = cell_start[c], end = cell_start[c + 1];
-        for (int i = beg + 1; i < end; ++i) {
-            const float4 v = sorted[i];
-            const int key = __float_as_int(v.w);
-            int j = i - 1;
-            while (j >= beg && __float_as_int(sorted[j].w) > key) { sorted[j + 1] = sorted[j]; --j; }
-            sorted[j + 1] = v;
-        }
+        int rank = 0;
+        for (int j = beg; j < end; ++j) rank += __float_as_int(arrived[j].w) < idx ? 1 : 0;
+        sorted[beg + rank] = v;
     }
 }
 
@@ -655,7 +657,7 @@ struct ws_neighbors_ws {
     DevBuf<CloudGrid> grids;
     DevBuf<float> bbox;
     DevBuf<int32_t> cell_of, cell_start, cursor, counts, scan_scratch, max_count;
-    DevBuf<float4> sorted;
+    DevBuf<float4> sorted, sorted_alt;      // (sorted_alt: the arrival-ordered copy the bin fill writes; see nb_cell_rank_kernel)
     DevBuf<int32_t> order;        // supports in cell order (work order of self-queries)
     bool self_query = false;      // queries == supports: walk the queries in cell order
     // state of the last plan
@@ -687,7 +689,7 @@ void ws_neighbors_ws_destroy(ws_neighbors_ws* ws)
     if (!ws) return;
     ws->grids.release(); ws->bbox.release(); ws->cell_of.release(); ws->cell_start.release();
     ws->cursor.release(); ws->counts.release(); ws->scan_scratch.release(); ws->max_count.release();
-    ws->sorted.release(); ws->order.release();
+    ws->sorted.release(); ws->sorted_alt.release(); ws->order.release();
     delete ws;
 }
 
@@ -755,6 +757,7 @@ static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, con
     if ((rc = ws->scan_scratch.ensure((size_t)ws_scan_scratch_items(cells + 1)))) return rc;
     if ((rc = ws->max_count.ensure(1))) return rc;
     if ((rc = ws->sorted.ensure((size_t)ns))) return rc;
+    if ((rc = ws->sorted_alt.ensure((size_t)ns))) return rc;
     if ((rc = ws->order.ensure((size_t)ns))) return rc;
 
     if (nb <= GRID_TABLE_MAX) {
@@ -777,12 +780,10 @@ static int nb_prepare(ws_neighbors_ws* ws, const float* queries, int64_t nq, con
     WS_LAUNCH_CHECK();
     if ((rc = ws_exclusive_scan_i32(ws->cell_start.p, ws->cell_start.p, cells, ws->scan_scratch.p, st))) return rc;
     WS_HIP(hipMemcpyAsync(ws->cursor.p, ws->cell_start.p, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToDevice, st));
-    nb_bin_fill_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(supports, ns, ws->cell_of.p, ws->cursor.p, ws->sorted.p);
+    nb_bin_fill_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(supports, ns, ws->cell_of.p, ws->cursor.p, ws->sorted_alt.p);
     WS_LAUNCH_CHECK();
-    // the bin fill hands out slots inside a cell through an atomic cursor (arrival order); sorting every cell's few entries
-    // by index makes the cell-sorted copy -- and with it the cell order and the summation order of the grid-walk backward
-    // (ws_kpconv_gather_bwd_x_grid) -- a pure function of the input: bit-identical gradients from run to run
-    nb_cell_sort_kernel<<<ws_grid(cells, 256), 256, 0, st>>>(ws->cell_start.p, cells, ws->sorted.p);
+    // entries of a cell in index order (the bin fill wrote them in arrival order): bit-identical grids from run to run
+    nb_cell_rank_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(ws->sorted_alt.p, ns, ws->cell_of.p, ws->cell_start.p, ws->sorted.p);
     WS_LAUNCH_CHECK();
     nb_order_kernel<<<ws_grid(ns, 256), 256, 0, st>>>(ws->sorted.p, ns, ws->order.p);
     WS_LAUNCH_CHECK();
