@@ -3,6 +3,7 @@
 // access is a coalesced row segment; the backward forms gather through the transposed table
 // (csr.hip) instead of the reference's scatter_add.
 #include "ws_common.h"
+#include <algorithm>
 #include "ws_bf16.h"
 
 namespace {
@@ -21,11 +22,32 @@ __device__ __forceinline__ int4 load_arg4(const uint8_t* p)
 // gathers are in flight per lane; shadow columns read nothing (zero row, blocks.py:104).
 // AT = the element type of the arg-max record: int32 (the C ABI), or uint8 inside the block calls when h <= 255 -- the
 // backward reads one arg piece per (incoming pair, row piece), 2.7 GB at level 0 with 4-byte elements
+// Work assignment of the vectorised pools.  ilv = 0: every workgroup takes one contiguous chunk of the (spatially ordered)
+// group list (ws_block_range).  ilv > 0 (workgroups per XCD; grid = 8 x ilv): the workgroups of an XCD walk ITS eighth of
+// the list together, group g = base + (local workgroup) * 4 + wave + t * (ilv * 4): at any moment the XCD works on ~ilv * 4
+// * S neighbouring queries, whose gathered rows fit its 4 MB L2 (with contiguous chunks the resident workgroups sit at
+// chunk starts spread over the whole cloud: every row came from the fabric again, FETCH_SIZE ~ the logical bytes).
+__device__ __forceinline__ void pool_groups(int64_t ngroups, int ilv, int wave, int64_t& g0, int64_t& gstep, int64_t& gend)
+{
+    if (ilv > 0 && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, lb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+        const int64_t per8 = (ngroups + 7) / 8;
+        const int64_t b8 = (int64_t)x * per8;
+        gend = b8 + per8 < ngroups ? b8 + per8 : ngroups;
+        g0 = b8 + (int64_t)lb * 4 + wave;
+        gstep = (int64_t)nbx * 4;
+    } else {
+        int64_t ibeg, iend;
+        ws_block_range(ngroups, ibeg, iend);
+        g0 = ibeg + wave; gstep = 4; gend = iend;
+    }
+}
+
 template <int G, typename T, typename AT = int32_t>
 __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restrict__ x, int64_t ns, int c,
                                                                 const int64_t* __restrict__ inds, int64_t nq, int h,
                                                                 T* __restrict__ out, AT* __restrict__ arg,
-                                                                const int32_t* __restrict__ order = nullptr)
+                                                                const int32_t* __restrict__ order = nullptr, int ilv = 0)
 {
     // order (optional): a spatially coherent permutation of the queries (the cell order of their level's search).  The
     // pooled points come out of the grid subsampling in hash-table order: walked by index, consecutive queries gather
@@ -34,9 +56,9 @@ __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restri
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane % G, slot = lane / G;
-    int64_t ibeg, iend;
-    ws_block_range(ws_ceil_div_dev(nq, S), ibeg, iend);
-    for (int64_t grp = ibeg + wave; grp < iend; grp += 4) {
+    int64_t g0, gstep, gend;
+    pool_groups(ws_ceil_div_dev(nq, S), ilv, wave, g0, gstep, gend);
+    for (int64_t grp = g0; grp < gend; grp += gstep) {
         const int64_t qi = grp * S + slot;
         const bool qok = qi < nq;
         const int64_t q = (qok && order) ? (int64_t)order[qi] : qi;
@@ -108,14 +130,15 @@ template <int G, typename T, typename AT = int32_t>
 __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restrict__ dy, const AT* __restrict__ arg,
                                                                 int h, int c, const int32_t* __restrict__ t_offsets,
                                                                 const int32_t* __restrict__ t_pairs, int64_t ns,
-                                                                T* __restrict__ dx, const int32_t* __restrict__ order = nullptr)
+                                                                T* __restrict__ dx, const int32_t* __restrict__ order = nullptr,
+                                                                int ilv = 0)
 {
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane % G, slot = lane / G;
-    int64_t ibeg, iend;
-    ws_block_range(ws_ceil_div_dev(ns, S), ibeg, iend);
-    for (int64_t grp = ibeg + wave; grp < iend; grp += 4) {
+    int64_t g0, gstep, gend;
+    pool_groups(ws_ceil_div_dev(ns, S), ilv, wave, g0, gstep, gend);
+    for (int64_t grp = g0; grp < gend; grp += gstep) {
         const int64_t si = grp * S + slot;
         const bool sok = si < ns;
         const int64_t s = (sok && order) ? (int64_t)order[si] : si;       // supports in their level's cell order (see the forward)
@@ -269,16 +292,27 @@ int max_pool_bwd_impl(const T* dy, const int32_t* arg, int64_t nq, int32_t h, in
     return WS_OK;
 }
 
+// workgroups per XCD of the interleaved assignment (0 = contiguous chunks; A/B switch WEASAL_POOL_INTERLEAVE).  Level-0 max-pool
+// of the DALES step (71 000 x 59 rows of 512 bytes): forward 245 -> 195 us in the step, 136 -> 97 us alone (tools/pool_lab.py)
+extern "C" int ws_pool_interleave = 256;
+static inline int pool_grid(int64_t groups, int ilv)
+{
+    if (ilv <= 0) return ws_grid(groups, 4);
+    const int64_t need = (groups + 31) / 32;              // never more workgroups per XCD than groups / 4 / 8
+    return 8 * (int)std::max<int64_t>(1, std::min<int64_t>(ilv, need));
+}
+
 // the block calls' private form: arg-max record in bytes (h <= 255, c % 4 == 0, aligned rows: the caller checks)
 int max_pool_fwd_u8_impl(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, float* out, uint8_t* arg,
                          const int32_t* order, hipStream_t st)
 {
     if (nq == 0) return WS_OK;
-    if (c <= 16) max_pool_fwd_vec_kernel<4, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 16), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
-    else if (c <= 32) max_pool_fwd_vec_kernel<8, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 8), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
-    else if (c <= 64) max_pool_fwd_vec_kernel<16, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 4), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
-    else if (c <= 128) max_pool_fwd_vec_kernel<32, float, uint8_t><<<ws_grid(ws_ceil_div(nq, 2), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
-    else max_pool_fwd_vec_kernel<64, float, uint8_t><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order);
+    const int ilv = order ? ws_pool_interleave : 0;       // (only with a spatial order is a neighbouring group a neighbouring place)
+    if (c <= 16) max_pool_fwd_vec_kernel<4, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 16), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (c <= 32) max_pool_fwd_vec_kernel<8, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 8), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (c <= 64) max_pool_fwd_vec_kernel<16, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 4), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (c <= 128) max_pool_fwd_vec_kernel<32, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 2), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else max_pool_fwd_vec_kernel<64, float, uint8_t><<<pool_grid(nq, ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
@@ -288,10 +322,11 @@ int max_pool_bwd_u8_impl(const float* dy, const uint8_t* arg, int64_t nq, int32_
 {
     (void)nq;
     if (ns == 0) return WS_OK;
-    if (c <= 32) max_pool_bwd_vec_kernel<8, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 8), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order);
-    else if (c <= 64) max_pool_bwd_vec_kernel<16, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 4), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order);
-    else if (c <= 128) max_pool_bwd_vec_kernel<32, float, uint8_t><<<ws_grid(ws_ceil_div(ns, 2), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order);
-    else max_pool_bwd_vec_kernel<64, float, uint8_t><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order);
+    const int ilv = order ? ws_pool_interleave : 0;       // (only with a spatial order is a neighbouring group a neighbouring place)
+    if (c <= 32) max_pool_bwd_vec_kernel<8, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 8), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    else if (c <= 64) max_pool_bwd_vec_kernel<16, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 4), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    else if (c <= 128) max_pool_bwd_vec_kernel<32, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 2), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    else max_pool_bwd_vec_kernel<64, float, uint8_t><<<pool_grid(ns, ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
