@@ -1099,10 +1099,39 @@ int64_t ws_gemm_xb_scratch_bytes(int64_t m, int32_t k, int32_t n)
     return 16 * m * (int64_t)n * (int64_t)sizeof(float);
 }
 
+// lab switch (tools/gemm_shapes.py): every product of a step timed on its own (events + synchronisation) and printed
+extern "C" int ws_gemm_log = 0;
+
+static int gemm_xb_core(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+                        const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
+                        float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream,
+                        int64_t brs, int64_t bcs, XbGate gate);
+
 static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                         const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
                         float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream,
                         int64_t brs = -1, int64_t bcs = 1, XbGate gate = XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f})
+{
+    if (!ws_gemm_log)
+        return gemm_xb_core(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream, brs, bcs, gate);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    WS_HIP(hipEventCreate(&e0)); WS_HIP(hipEventCreate(&e1));
+    WS_HIP(hipEventRecord(e0, st));
+    const int rc = gemm_xb_core(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream, brs, bcs, gate);
+    WS_HIP(hipEventRecord(e1, st));
+    WS_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    WS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    fprintf(stderr, "GEMMLOG xb m=%lld k=%d n=%d us=%.1f tflops=%.1f\n", (long long)m, k, n, ms * 1e3, 2.0 * m * k * n / (ms * 1e-3) / 1e12);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
+static int gemm_xb_core(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
+                        const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
+                        float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream,
+                        int64_t brs, int64_t bcs, XbGate gate)
 {
     if (brs < 0) brs = n;                       // row-major [K,N]
     WS_REQUIRE(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
@@ -1293,8 +1322,29 @@ int64_t ws_gemm_xty_scratch_bytes(int64_t m, int32_t k, int32_t n)
     return ws_ceil_div(m > 0 ? m : 1, chunk) * (int64_t)k * n * (int64_t)sizeof(float);
 }
 
+static int gemm_xty_core(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
+                         float* out, void* scratch, void* stream);
+
 int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
                 float* out, void* scratch, void* stream)
+{
+    if (!ws_gemm_log) return gemm_xty_core(x, m, k, ldx, y, n, ldy, out, scratch, stream);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    WS_HIP(hipEventCreate(&e0)); WS_HIP(hipEventCreate(&e1));
+    WS_HIP(hipEventRecord(e0, st));
+    const int rc = gemm_xty_core(x, m, k, ldx, y, n, ldy, out, scratch, stream);
+    WS_HIP(hipEventRecord(e1, st));
+    WS_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    WS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    fprintf(stderr, "GEMMLOG xty m=%lld k=%d n=%d us=%.1f tflops=%.1f\n", (long long)m, k, n, ms * 1e3, 2.0 * m * k * n / (ms * 1e-3) / 1e12);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
+static int gemm_xty_core(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
+                         float* out, void* scratch, void* stream)
 {
     WS_REQUIRE(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
     WS_REQUIRE(out, "NULL argument");
