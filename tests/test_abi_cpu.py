@@ -191,3 +191,38 @@ def test_facades_raise_in_a_forked_child_of_a_gpu_parent(monkeypatch):
     for m in msgs:
         assert m == _device.FORK_MESSAGE and "spawn" in m
     assert not _device._forked_from_gpu_parent     # the parent itself is unaffected
+
+
+def test_pyramid_descriptor_mirror_and_schedule():
+    """the ctypes mirror of `struct ws_pyramid_desc` has the library's size, and the per-level plan handed to
+    ws_pyramid_build is the schedule of datasets/common.py:487-545 (radii double per level, the deformable radius where a
+    level holds deformable blocks, pooling everywhere but on the last level)"""
+    import ctypes as C
+    from weasal_amd import _lib, config as wcfg, pyramid
+    assert C.sizeof(pyramid.PyramidDesc) == _lib.lib().ws_pyramid_desc_bytes()
+    for cfg in (wcfg.DALESPLConfig(), wcfg.Vaihingen3DPLConfig(), wcfg.Vaihingen3DWLConfig(), wcfg.DALESDeformConfig()):
+        levels = pyramid._schedule(cfg, [1] * 8)
+        assert len(levels) == cfg.num_layers
+        r = cfg.first_subsampling_dl * cfg.conv_radius
+        for l, lv in enumerate(levels):
+            deform_here = any('deformable' in b for b in _blocks_of_level(cfg, l))
+            want = r * cfg.deform_radius / cfg.conv_radius if deform_here else r
+            assert lv["conv_on"] and abs(lv["r_conv"] - want) < 1e-12
+            assert lv["pool_on"] == (l + 1 < len(levels))
+            if lv["pool_on"]:
+                assert abs(lv["dl"] - 2 * r / cfg.conv_radius) < 1e-12 and abs(lv["r_up"] - 2 * lv["r_pool"]) < 1e-12
+            r *= 2
+
+
+def _blocks_of_level(cfg, level):
+    out, cur, l = [], [], 0
+    for b in cfg.architecture:
+        if any(t in b for t in ('pool', 'strided', 'global', 'upsample')):
+            if l == level:
+                return cur
+            cur, l = [], l + 1
+            if 'global' in b or 'upsample' in b:
+                break
+        else:
+            cur.append(b)
+    return out

@@ -373,3 +373,64 @@ def test_deformable_modulated_network_steps():
     assert np.isfinite(losses).all() and torch.isfinite(out).all()
     after = dict(net.named_parameters())
     assert any(not torch.equal(before[n], after[n].detach()) for n in before)
+
+
+@pytest.mark.gpu
+def test_one_call_pyramid_equals_the_per_call_loop():
+    """ws_pyramid_build (one library call per batch) against the per-call loop of pyramid.segmentation_inputs on the same
+    inputs and the same np.random stream: points, index matrices, lengths, cell orders, search grids and transposed tables
+    bit-identical; also after a deliberately tiny arena (the WS_ERR_CAPACITY round trip)"""
+    from weasal_amd import config as wcfg, pyramid, synthetic
+    dev = torch.device("cuda:0")
+    for name, cfgn in (("vaihingen", "Vaihingen3DPLConfig"), ("dales_deform", "DALESDeformConfig")):
+        wl = synthetic.WORKLOADS[name]
+        cfg = getattr(wcfg, cfgn)()
+        spheres, points = (3, 2500) if name == "vaihingen" else (2, 6000)
+        pts, feats, labels, lens = synthetic.make_inputs(5, spheres, points, wl["radius"] * (0.45 if name == "dales_deform" else 1.0),
+                                                         cfg.in_features_dim)
+        args = (cfg, torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev), lens, wl["limits"])
+        batches = []
+        for native, tiny in ((False, False), (True, False), (True, True)):
+            pyramid.NATIVE_PYRAMID = native
+            if tiny:
+                pyramid._arena_hint.clear()
+                real_schedule = pyramid._schedule
+                pyramid._arena_hint.update({k: 1 for k in []})
+                # make the first guess hopeless: one byte per key is not enough for anything
+                import threading
+                key = (dev.index or 0, threading.get_ident(), int(args[1].shape[0]), tuple(int(v) for v in wl["limits"]), len(real_schedule(cfg, wl["limits"])))
+                pyramid._arena_hint[key] = 1
+            try:
+                np.random.seed(9)
+                batches.append(pyramid.build_batch(*args))
+            finally:
+                pyramid.NATIVE_PYRAMID = True
+        torch.cuda.synchronize()
+        ref = batches[0]
+        for got in batches[1:]:
+            for a, b in zip(ref.points + ref.neighbors + ref.pools + ref.upsamples + ref.lengths,
+                            got.points + got.neighbors + got.pools + got.upsamples + got.lengths):
+                assert a.shape == b.shape and torch.equal(a, b)
+            assert len(ref.point_orders) == len(got.point_orders)
+            for (_, oa), (_, ob) in zip(ref.point_orders, got.point_orders):
+                assert torch.equal(oa, ob)
+            assert len(ref.search_grids) == len(got.search_grids)
+            for (ma, ga), (mb, gb) in zip(ref.search_grids, got.search_grids):
+                assert torch.equal(ma, mb) and torch.equal(ga.key_last, gb.key_last)
+                # the exported grid: [CloudGrid nb | cell_start cells + 2 | sorted ns] at 256-byte aligned offsets (csrc/ws_grid.h);
+                # the gaps between the sections are never written
+                al = lambda v: (v + 255) // 256 * 256
+                c_off = al(ga.nb * 52)
+                s_off = c_off + al((ga.cells + 2) * 4)
+                for lo, hi in ((0, ga.nb * 52), (c_off, c_off + (ga.cells + 1) * 4), (s_off, s_off + ga.ns * 16)):
+                    assert torch.equal(ga.blob[lo:hi], gb.blob[lo:hi]), (lo, hi)
+                assert (ga.nb, ga.cells, ga.ns, ga.max_count, ga.cap) == (gb.nb, gb.cells, gb.ns, gb.max_count, gb.cap)
+                assert abs(ga.radius - gb.radius) == 0.0
+            for ta, tb in ((ref.tables, got.tables), (ref.col0_tables, got.col0_tables)):
+                assert len(ta) == len(tb)
+                for (ma, nsa, xa), (mb, nsb, xb) in zip(ta, tb):
+                    assert nsa == nsb and torch.equal(ma, mb)
+                    assert torch.equal(xa.offsets[:nsa + 1], xb.offsets[:nsb + 1])
+                    n_pairs = int(xa.offsets[nsa])
+                    assert torch.equal(xa.pairs[:n_pairs], xb.pairs[:n_pairs])
+            assert [float(r) for _, r in ref.search_radii] == [float(r) for _, r in got.search_radii]

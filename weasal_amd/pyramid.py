@@ -313,7 +313,7 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
         else:                                          # a row beyond the asynchronous search's slab
             mat = ops.radius_neighbors(q, s, ql, sl, radius, limit=width, dtype=torch.int64)
         if search_radii is not None:
-            search_radii.append((mat, float(np.float32(radius))))
+            search_radii.append((mat, float(radius)))
         return mat, mc
 
     neighbors, pools, upsamples = [], [], []
