@@ -592,6 +592,11 @@ int64_t ws_potentials_scratch_bytes(int64_t n);
 int ws_potentials_update(const float* pot_points, int64_t n, const double* h_center, double radius, double* potentials,
                          double* out_min, int64_t* out_argmin, void* scratch, void* stream);
 
+/* nn.Dropout on the decoder output in front of the head, training mode (models/architectures.py:345-346): out[i] = keep(i) ? in[i] / (1 - p) : 0,
+ * keep(i) a pure function of (seed, i) (counter-based; Bernoulli(1 - p)): the backward is the same call on the incoming
+ * gradient with the same seed, no mask is stored.  in / out float32 [n], 16-byte aligned; in == out allowed. */
+int ws_dropout_apply(const float* in, int64_t n, float p, uint64_t seed, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * The two ends of the training step around the network (forward + backward + SGD).
  * ws_softmax_ce_fwd / _bwd: models/architectures.py:362-373 (KPFCNN.loss) -- the label mapping (:362-365; lut [lut_n]

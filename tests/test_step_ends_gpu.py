@@ -142,3 +142,32 @@ def test_run_ahead_limiter_reports_a_set_capacity_flag(gpu):
     lim.tick(batch(300, grids=2))
     with pytest.raises(RuntimeError, match="300"):
         lim.finish()
+
+
+@pytest.mark.gpu
+def test_dropout_kernel_mask_statistics_and_backward():
+    """ops.dropout (ws_dropout_apply): Bernoulli(1 - p) keep mask from (seed, index), kept values scaled by 1 / (1 - p), the
+    backward applies the SAME mask (recomputed, not stored); a seed reproduces the mask, another seed gives another"""
+    from weasal_amd import ops
+    dev = torch.device("cuda:0")
+    x = (torch.rand(400_003, 7, device=dev) + 0.5).requires_grad_(True)     # no zeros; size not a multiple of 4
+    for p in (0.5, 0.1):
+        y = ops.dropout(x, p, seed=1234)
+        kept = y != 0
+        frac = float(kept.float().mean())
+        assert abs(frac - (1 - p)) < 4 * (p * (1 - p) / x.numel()) ** 0.5 + 1e-4, (p, frac)
+        assert torch.equal(y[kept], (x.detach() * (1.0 / (1.0 - p)))[kept])
+        g = torch.randn_like(y)
+        (dx,) = torch.autograd.grad(y, x, g)
+        assert torch.equal(dx != 0, kept & (g != 0))
+        assert torch.equal(dx[kept], (g * (1.0 / (1.0 - p)))[kept])
+        assert torch.equal(ops.dropout(x, p, seed=1234), y)
+        other = ops.dropout(x, p, seed=1235) != 0
+        assert 0.2 < float((other != kept).float().mean()) / (2 * p * (1 - p)) < 5.0
+        # no structure along rows or columns (a counter-based generator must not alias with the row length)
+        assert float(kept.float().mean(0).std()) < 0.01 and float(kept.float().mean(1).std()) < 0.5
+    assert torch.equal(ops.dropout(x, 0.0, seed=5), x.detach())
+    torch.manual_seed(3)
+    a = ops.dropout(x, 0.5)
+    torch.manual_seed(3)
+    assert torch.equal(ops.dropout(x, 0.5), a)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "ws_contrast_rows_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp]),
     "ws_launch_count": (_i64, []),
+    "ws_dropout_apply": (C.c_int, [_vp, _i64, C.c_float, C.c_uint64, _vp, _vp]),
     "ws_pyramid_build": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ws_pyramid_desc_bytes": (_i64, []),
     "ws_contrast_head_scratch_bytes": (_i64, [_i64]),

@@ -20,6 +20,7 @@ from .blocks import KPConv, NearestUpsampleBlock, UnaryBlock, block_decider, clo
 
 _LAYER_CHANGE = ('pool', 'strided', 'upsample', 'global')
 REGULARIZER_KERNEL = os.environ.get("WEASAL_REG_KERNEL", "1") != "0"      # A/B switch: 0 = the torch-op form below
+DROPOUT_KERNEL = os.environ.get("WEASAL_DROPOUT_KERNEL", "1") != "0"       # A/B switch: 0 = nn.Dropout (the framework's kernels)
 CONTRAST_KERNELS = os.environ.get("WEASAL_CONTRAST_KERNELS", "1") != "0"  # A/B switch: 0 = contrast_loss's head / tail as torch ops
 
 
@@ -171,7 +172,10 @@ class KPFCNN(nn.Module):
             x = block_op(x, batch)
             block_i += 1
         if self.dropout:
-            x = self.droplayer(x)
+            if DROPOUT_KERNEL and self.training and x.is_cuda and x.dtype == torch.float32 and x.requires_grad:
+                x = ops.dropout(x, float(self.dropout))          # one pass each way, mask recomputed instead of stored
+            else:
+                x = self.droplayer(x)
         x = self.head_mlp(x, batch)
         return self.head_softmax(x, batch)
 

@@ -1167,6 +1167,37 @@ class _SoftmaxCE(torch.autograd.Function):
         return d, None, None, None
 
 
+class _Dropout(torch.autograd.Function):
+    """nn.Dropout(p) in training mode as one pass each way (ws_dropout_apply): the keep mask is a function of (seed, index)
+    and is recomputed by the backward instead of stored"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        check(_lib.lib().ws_dropout_apply(ptr(x), x.numel(), float(p), int(seed), ptr(out), current_stream()))
+        ctx.p, ctx.seed = float(p), int(seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        check(_lib.lib().ws_dropout_apply(ptr(g), g.numel(), ctx.p, ctx.seed, ptr(out), current_stream()))
+        return out, None, None
+
+
+def dropout(x, p, seed=None):
+    """training-mode dropout of a float32 device tensor; `seed` defaults to a draw from torch's default (CPU) generator, so
+    torch.manual_seed makes a run reproducible"""
+    _need_cuda(x)
+    if x.dtype != torch.float32:
+        raise _lib.WeasalHipError("dropout takes float32 tensors (got %s)" % x.dtype)
+    if seed is None:
+        seed = int(torch.randint(0, 1 << 62, (1,)).item())
+    return _Dropout.apply(x, p, seed)
+
+
 def cross_entropy(logits, labels, lut=None, weight=None):
     """KPFCNN.loss's criterion (models/architectures.py:362-373): `lut` [V+2] int64 maps raw label values to class
     positions (last entry: the spare -1 of out-of-table labels; None = labels are positions already, < 0 ignored), then
