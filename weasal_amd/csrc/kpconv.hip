@@ -10,9 +10,12 @@
 // The structure of K3/K4 (entry pool in LDS, branch-free flush, scheduling order) is described
 // above the kernels.
 #include "ws_common.h"
+#include <algorithm>
 #include "ws_grid.h"
 #include "ws_bf16.h"
 
+extern "C" int ws_kpconv_table_interleave;
+extern "C" int ws_kpconv_grid_interleave;
 namespace {
 
 constexpr float WS_SHADOW = 1e6f;
@@ -37,6 +40,7 @@ struct GeomParams {
     const float* rmax;    // K4G, MODE 2: device float = max over the queries of (max_k |kp_k|), written by
                           // ws_kpconv_deform_prepare: a pair farther apart than that + extent has no influence (NULL: no bound)
     int cut;              // pool-form K3 (MODE 0): 1 = rows are sorted by distance, stop at the influence reach (see CUT)
+    int ilv;              // K4G: workgroups per XCD of the interleaved item assignment (ws_wave_items), 0 = contiguous chunks
 };
 
 // Influence of the K kernel points on one neighbour offset n = s - q.  kp is wave-uniform.
@@ -1079,9 +1083,9 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_kernel(
         for (int t = 0; t < 3 * K; ++t) kpr[t] = kernel_points[t];
     }
 
-    int64_t ibeg, iend;
-    ws_block_range(ns, ibeg, iend);
-    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+    int64_t item0, istep, iend;
+    ws_wave_items(ns, order ? g.ilv : 0, wave, item0, istep, iend);
+    for (int64_t item = item0; item < iend; item += istep) {
         const int64_t s = order ? (int64_t)order[item] : item;
         const float sx = s_pts[3 * s + 0], sy = s_pts[3 * s + 1], sz = s_pts[3 * s + 2];
         const int beg = t_offsets[s], end = t_offsets[s + 1];
@@ -1586,10 +1590,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_grid_kernel(
         for (int t = 0; t < 3 * K; ++t) kpr[t] = kernel_points[t];
     }
 
-    int64_t ibeg, iend;
-    ws_block_range(ns, ibeg, iend);
+    int64_t item0, istep, iend;
+    ws_wave_items(ns, order ? g.ilv : 0, wave, item0, istep, iend);
     CloudGrid gr = grids[0];        // supports come cloud by cloud: the element's grid stays in registers
-    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+    for (int64_t item = item0; item < iend; item += istep) {
         const int64_t s = order ? (int64_t)order[item] : item;
         if (s < gr.s_base || s >= gr.s_base + gr.s_len) {
             int b = 0;
@@ -2114,6 +2118,8 @@ int ws_kpconv_gs = 0;
 extern "C" int ws_kpconv_grid_rows;       // diagnostics: 0 = K4G always walks the cell grid (WEASAL_K4G_ROWS=0)
 int ws_kpconv_grid_rows = 1;
 extern "C" int ws_kpconv_grid_sorted;     // 1: ws_kpconv_gather_bwd_x_grid sums the incoming pairs in index order (the pair order of
+extern "C" int ws_kpconv_table_interleave = 0;    // the same for the transposed-table K4 (WEASAL_K4_INTERLEAVE)
+extern "C" int ws_kpconv_grid_interleave = 512;   // lab: workgroups per XCD of the interleaved assignment (WEASAL_K4G_INTERLEAVE)
 int ws_kpconv_grid_sorted = 0;            //    the transposed table: bit-identical to ws_kpconv_gather_bwd_x); 0: in grid-walk order
 
 namespace {
@@ -2234,7 +2240,8 @@ int gather_bwd_x_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_
     WS_REQUIRE(nq * (int64_t)k * ci < (1ll << 31), "nq*k*ci exceeds the 32-bit row offsets of the gather");
     GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, gate, gate_slope, nullptr, 0};
     hipStream_t st = (hipStream_t)stream;
-    const int grid = ws_grid(ns, 4);
+    g.ilv = order ? ws_kpconv_table_interleave : 0;
+    const int grid = g.ilv > 0 ? 8 * (int)std::max<int64_t>(1, std::min<int64_t>(g.ilv, ws_ceil_div(ns, 32))) : ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
     WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
 #define WS_BWD2(G, MODEV, VECV)                                                                                       \
@@ -2308,7 +2315,8 @@ int gather_bwd_x_grid_impl(const float* s_pts, int64_t ns, const void* grid_blob
     const float4* sorted = (const float4*)(base + ws_grid_blob_sorted_off(nb, cells));
     const float r2 = radius * radius;                       // neighbors.cpp:226, as in the search
     const unsigned long long* kl = reinterpret_cast<const unsigned long long*>(key_last);
-    const int grid = ws_grid(ns, 4);
+    g.ilv = order ? ws_kpconv_grid_interleave : 0;
+    const int grid = g.ilv > 0 ? 8 * (int)std::max<int64_t>(1, std::min<int64_t>(g.ilv, ws_ceil_div(ns, 32))) : ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
     WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
 #define WS_BWDG2(G, MODEV, VECV)                                                                                     \

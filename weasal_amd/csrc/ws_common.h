@@ -79,6 +79,25 @@ __device__ __forceinline__ void ws_block_range(int64_t n_items, int64_t& beg, in
     end = beg + per < n_items ? beg + per : n_items;
     if (beg > n_items) beg = n_items;
 }
+// Items of this WAVE (workgroups of 4 waves): i0, i0 + step, ... < end.  ilv = 0: the workgroup's contiguous chunk
+// (ws_block_range).  ilv > 0 (grid = 8 x ilv workgroups): the workgroups of an XCD walk ITS eighth of the spatially ordered
+// list together -- item = base + 4 * (local workgroup) + wave + t * 4 * ilv -- so that the rows gathered by the workgroups
+// resident at one moment overlap and stay in the XCD's L2 (see pools.hip).
+__device__ __forceinline__ void ws_wave_items(int64_t n_items, int ilv, int wave, int64_t& i0, int64_t& step, int64_t& end)
+{
+    if (ilv > 0 && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, lb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+        const int64_t per8 = (n_items + 7) / 8;
+        const int64_t b8 = (int64_t)x * per8;
+        end = b8 + per8 < n_items ? b8 + per8 : n_items;
+        i0 = b8 + (int64_t)lb * 4 + wave;
+        step = (int64_t)nbx * 4;
+    } else {
+        int64_t ibeg, iend;
+        ws_block_range(n_items, ibeg, iend);
+        i0 = ibeg + wave; step = 4; end = iend;
+    }
+}
 __device__ __forceinline__ float ws_wave_sum(float v)
 {
 #pragma unroll
