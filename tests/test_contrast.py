@@ -166,3 +166,33 @@ def test_contrast_slice_duplicates_gradient():
     assert len(torch.unique(slc)) == valid
     assert abs(lk - lt) <= 2e-6 * max(1.0, abs(lt))
     assert float((gk - gt).abs().max()) <= 2e-5 * float(gt.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c", [(37, 9), (300, 16), (1000, 4), (5000, 13)])
+def test_contrast_small_and_wide_inputs(n, c):
+    """fewer points than one workgroup handles, fewer points than slice slots, the widest supported logits (C = 16): the
+    kernels against the torch-op form"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n + c)
+    outputs = torch.randn(n, c, generator=g) * 1.5
+    labels = torch.full((n,), 100, dtype=torch.int64)
+    idx = torch.randperm(n, generator=g)[:max(1, n // 5)]
+    labels[idx] = torch.randint(0, min(c, 9), (idx.numel(),), generator=g)
+    (lk, gk, pk, slc), (lt, gt, pt, _) = _both_forms(dev, outputs, labels, 30, seed=7)
+    assert slc.shape == (1000,) and int(slc.max()) < n
+    assert abs(lk - lt) <= 5e-6 * max(1.0, abs(lt)), (lk, lt)
+    assert float((gk - gt).abs().max()) <= 5e-5 * max(float(gt.abs().max()), 1e-12)
+
+
+@pytest.mark.gpu
+def test_contrast_nothing_valid_gives_zero_loss_and_gradient():
+    dev = torch.device("cuda:0")
+    outputs, labels = _case(2, 800, 0, 0.01)
+    cfg = wcfg.DALESPLConfig()
+    cfg.contrast_thd = 99
+    o = outputs.to(dev).requires_grad_(True)
+    net = KPFCNN.__new__(KPFCNN)
+    loss = KPFCNN.contrast_loss(net, o, labels.to(dev), cfg)
+    loss.backward()
+    assert float(loss) == 0.0 and float(o.grad.abs().max()) == 0.0

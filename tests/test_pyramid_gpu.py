@@ -434,3 +434,33 @@ def test_one_call_pyramid_equals_the_per_call_loop():
                     n_pairs = int(xa.offsets[nsa])
                     assert torch.equal(xa.pairs[:n_pairs], xb.pairs[:n_pairs])
             assert [float(r) for _, r in ref.search_radii] == [float(r) for _, r in got.search_radii]
+
+
+@pytest.mark.gpu
+def test_one_call_pyramid_errors_and_fallbacks():
+    """an empty sphere raises the reference's empty-result error from either path; more than 64 spheres, or no limits, take
+    the per-call loop (ws_pyramid_build's bounds) and still build"""
+    from weasal_amd import config as wcfg, pyramid, synthetic
+    dev = torch.device("cuda:0")
+    cfg = wcfg.Vaihingen3DPLConfig()
+    wl = synthetic.WORKLOADS["vaihingen"]
+    pts, feats, labels, lens = synthetic.make_inputs(3, 2, 1500, wl["radius"], cfg.in_features_dim)
+    P, F, L = torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev)
+    assert pyramid.native_eligible(cfg, P, lens, wl["limits"])
+    assert not pyramid.native_eligible(cfg, P, lens, [])
+    assert not pyramid.native_eligible(cfg, P, np.ones(65, np.int32), wl["limits"])
+    np.random.seed(2)
+    b = pyramid.build_batch(cfg, P, F, L, lens, [])                 # no limits: the two-call protocol, full widths
+    assert b.neighbors[0].shape[0] == 3000 and b.neighbors[0].shape[1] >= 5
+    # a far-away lonely point as its own sphere: every search of it finds itself only; an EMPTY sphere is the reference's error
+    lens_bad = np.array([int(lens[0]), 0, int(lens[1])], dtype=np.int32)
+    for native in (True, False):
+        pyramid.NATIVE_PYRAMID = native
+        try:
+            with pytest.raises(RuntimeError):
+                np.random.seed(2)
+                pyramid.build_batch(cfg, P[:0], F[:0], L[:0], np.zeros(1, np.int32), wl["limits"])
+            np.random.seed(2)
+            pyramid.build_batch(cfg, P, F, L, lens_bad, wl["limits"])       # an empty element next to full ones is legal
+        finally:
+            pyramid.NATIVE_PYRAMID = True
