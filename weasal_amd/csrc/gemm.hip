@@ -221,6 +221,65 @@ __device__ __forceinline__ void xb_rows_epilogue(const f32x16 (&acc)[NT], int64_
     }
 }
 
+// The same epilogue with the wave's 32 x 32 tile turned through LDS first.  In the rows-on-lanes layout a store instruction
+// writes 16 bytes to each of 32 DIFFERENT rows (two column quads): a row's 128-byte line is completed by four separate
+// instructions, and residual rows are read the same way -- products whose traffic is their output (K = 32 .. 64) ran at
+// 2.5-3.3 TB/s where read-dominated ones reach 4.4-5.2 (tools/gemm_small_k_lab.py).  Staged: lane (r = lane / 8, c = lane % 8)
+// owns the float4 at row r + 8 p, columns 4 c .. 4 c + 3 of the tile: one instruction moves 8 whole 128-byte row segments.
+// `stage`: wave-private [32][36] floats (the W buffers, free after the main loop).
+constexpr int XB_STAGE_LD = 36;
+constexpr int XB_STAGE_FLOATS = 32 * XB_STAGE_LD;
+template <int NT>
+__device__ __forceinline__ void xb_rows_epilogue_staged(const f32x16 (&acc)[NT], int64_t row0, int64_t m, int n0, int n, int lane,
+                                                        float* __restrict__ y, int64_t ldy, const float* __restrict__ bias,
+                                                        const float* __restrict__ residual, int64_t ldr, int act, float slope,
+                                                        const XbGate& gate, float* __restrict__ stage)
+{
+    const int idx = lane & 31, h = lane >> 5;
+    const int r8 = lane >> 3, c4 = lane & 7;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(&stage[idx * XB_STAGE_LD + 8 * g + 4 * h]) =
+                make_float4(acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int col = n0 + 32 * i + 4 * c4;
+        const int colc = col < n ? col : n - 4;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bq = *reinterpret_cast<const float4*>(bias + colc);
+        float4 v[4], rq[4];
+        int64_t rr[4];
+        bool live[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int rl = r8 + 8 * p;
+            const int64_t row = row0 + rl;
+            live[p] = row < m && col < n;
+            rr[p] = row < m ? row : m - 1;
+            v[p] = *reinterpret_cast<const float4*>(&stage[rl * XB_STAGE_LD + 4 * c4]);
+            rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (residual) rq[p] = *reinterpret_cast<const float4*>(residual + rr[p] * ldr + colc);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            v[p].x = (v[p].x + rq[p].x) + bq.x; v[p].y = (v[p].y + rq[p].y) + bq.y;      // residual first, then bias: the order of
+            v[p].z = (v[p].z + rq[p].z) + bq.z; v[p].w = (v[p].w + rq[p].w) + bq.w;      // xb_rows_epilogue (bit-identical results)
+            if (act) {
+                v[p].x = v[p].x > 0.0f ? v[p].x : v[p].x * slope;
+                v[p].y = v[p].y > 0.0f ? v[p].y : v[p].y * slope;
+                v[p].z = v[p].z > 0.0f ? v[p].z : v[p].z * slope;
+                v[p].w = v[p].w > 0.0f ? v[p].w : v[p].w * slope;
+            }
+            if (gate.y || gate.mask) xb_gate4(v[p], gate, rr[p], colc);
+            if (live[p]) *reinterpret_cast<float4*>(y + rr[p] * ldy + col) = v[p];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // gemm_xb2: same product, "rows on the lanes".  The MFMA is fed transposed: A operand = the small
 // matrix (i = output column), B operand = X (j = row of X), so that
@@ -240,7 +299,7 @@ template <int NT, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_xb2_kernel(
     const float* __restrict__ x, int64_t m, int k, int64_t ldx, const float* __restrict__ b, int n, int ldb, int bcs,
     float* __restrict__ y, int64_t ldy, const float* __restrict__ bias, const float* __restrict__ residual, int64_t ldr,
-    int act, float slope, int csplit, float* __restrict__ partial, const XbGate gate)
+    int act, float slope, int csplit, float* __restrict__ partial, const XbGate gate, int staged)
 {
     // split-K (gridDim.z > 1; few rows, deep k): workgroup z contracts chunks [z*csplit, (z+1)*csplit) and
     // writes its raw sums to partial[z][m][n]; splitk_epilogue_kernel adds them in a fixed order
@@ -249,7 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     constexpr int BN = 32 * CT;
     constexpr int KC = 32;
     constexpr int WBUF = CT * 1024;                       // floats per W chunk buffer
-    __shared__ __attribute__((aligned(16))) float Ws[2 * WBUF];
+    constexpr int WS_FLOATS = 2 * WBUF > 4 * XB_STAGE_FLOATS ? 2 * WBUF : 4 * XB_STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float Ws[WS_FLOATS];
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -359,6 +419,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
             }
         }
         __syncthreads();
+    }
+    if (staged) {
+        // (the main loop ended on a barrier: nobody reads the W buffers any more)
+        const int64_t row0 = (int64_t)blockIdx.x * (32 * WM) + wm * 32;
+        float* stage = &Ws[wave * XB_STAGE_FLOATS];
+        if (partial)
+            xb_rows_epilogue_staged<NT>(acc, row0, m, n0 + wn * (32 * NT), n, lane, partial + (int64_t)blockIdx.z * m * n, n, nullptr,
+                                        nullptr, 0, 0, 0.0f, XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f}, stage);
+        else
+            xb_rows_epilogue_staged<NT>(acc, row0, m, n0 + wn * (32 * NT), n, lane, y, ldy, bias, residual, ldr, act, slope, gate, stage);
+        return;
     }
     if (partial)
         xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, partial + (int64_t)blockIdx.z * m * n, n, nullptr, nullptr, 0,
@@ -1083,6 +1154,7 @@ extern "C" {
 
 // diagnostic switches of tools/gemm_lab.cpp (not part of the drop-in surface of include/weasal_hip.h)
 int ws_gemm_wave_cols = 0;  // forced wave grid of gemm_xb2 (column groups 1 / 2), 0 = automatic
+int ws_gemm_staged = 1;     // gemm_xb2 epilogue: 1 = the tile turned through LDS (whole 128-byte row segments per store), 0 = per-lane rows
 int ws_gemm_variant = 2;    // 1 = LDS-staged tiles (gemm_xb / gemm_xty), 2 = operands straight from global memory
 #ifdef WS_LAB_SPLIT_GEMM
 int ws_gemm_split = 0;      // 0 = the f32-input MFMA (default: the benchmark's fp32 numbers are measured on it);
@@ -1165,7 +1237,7 @@ static int gemm_xb_core(const float* x, int64_t m, int32_t k, int64_t ldx, const
         splits = (int)ws_ceil_div(nch, csplit);                                                                 \
         float* part = splits > 1 ? (float*)scratch : nullptr;                                                   \
         gemm_xb2_kernel<NTV, WNV><<<dim3(gx2, gy2, (unsigned)splits), 256, 0, st>>>(x, m, k, ldx, b, n, (int)brs, (int)bcs, y, ldy, bias, residual, \
-                                                                                    ldr, act, slope, csplit, part, gate);   \
+                                                                                    ldr, act, slope, csplit, part, gate, ws_gemm_staged);   \
         if (splits > 1)                                                                                         \
             splitk_epilogue_kernel<<<ws_grid(m * (n / 4), 256), 256, 0, st>>>(part, splits, m, n, y, ldy, bias, residual, ldr, \
                                                                               act, slope, gate);                \
