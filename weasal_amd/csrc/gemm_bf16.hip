@@ -20,22 +20,29 @@
 #include "ws_common.h"
 #include "ws_bf16.h"
 
+extern "C" int ws_gemm_staged;      // gemm.hip: 1 = epilogues turned through LDS
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ bool ws_bf16_staged_flag(int s) { return s != 0; }
+
 template <int NT, bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_xbt_bf16_kernel(
     const bf16_t* __restrict__ x, int64_t m, int k, int64_t ldx, const bf16_t* __restrict__ bt, int n, int64_t ldbt,
     void* __restrict__ yv, int64_t ldy, const float* __restrict__ bias, const bf16_t* __restrict__ residual, int64_t ldr,
-    int act, float slope, int vecout)
+    int act, float slope, int vecout, int staged)
 {
     constexpr int BN = 32 * NT;
     constexpr int KC = 32;                         // k per chunk (two MFMA steps of 16)
     constexpr int ROWB = 80;                       // bytes per staged Bt row: 64 + 16 of padding
     constexpr int BP = (BN * 4 + 255) / 256;       // 16-byte pieces of the Bt chunk per thread
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][BN * ROWB];
+    constexpr int STAGE_LD = 36, STAGE_BYTES = 4 * 32 * STAGE_LD * 4;        // epilogue: one [32][36] float tile per wave
+    constexpr int BS_BYTES = 2 * BN * ROWB > STAGE_BYTES ? 2 * BN * ROWB : STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs_raw[BS_BYTES];
+    unsigned char (*Bs)[BN * ROWB] = reinterpret_cast<unsigned char (*)[BN * ROWB]>(Bs_raw);
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63;
@@ -107,6 +114,46 @@ __global__ __launch_bounds__(256) void gemm_xbt_bf16_kernel(
         __syncthreads();
     }
 
+    if (vecout && (n & 3) == 0 && ws_bf16_staged_flag(staged)) {
+        // the wave's 32 x 32 tile turned through LDS (see gemm.hip, xb_rows_epilogue_staged): lane (r = lane / 8, c = lane % 8)
+        // stores columns 4 c .. 4 c + 3 of rows r + 8 p -- 8 row segments of 64 (bf16) / 128 (f32) contiguous bytes per
+        // instruction instead of 8 / 16 bytes to each of 32 rows.  Same arithmetic in the same order.
+        float* stage = reinterpret_cast<float*>(Bs_raw) + wave * (32 * STAGE_LD);
+        const int r8 = lane >> 3, c4 = lane & 7;
+        const int64_t row0 = brow0 + wave * 32;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&stage[j * STAGE_LD + 8 * g + 4 * h]) =
+                    make_float4(acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int col = n0 + 32 * i + 4 * c4;
+            if (col < n) {
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias) b4 = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int rl = r8 + 8 * p;
+                    const int64_t row = row0 + rl;
+                    if (row >= m) continue;
+                    const float4 a = *reinterpret_cast<const float4*>(&stage[rl * STAGE_LD + 4 * c4]);
+                    float v[4] = {a.x + b4.x, a.y + b4.y, a.z + b4.z, a.w + b4.w};
+                    if (residual) { const float4 r4 = ld4(residual + row * ldr + col); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                    if (act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : v[e] * slope;
+                    }
+                    if (OUT_F32) st4(reinterpret_cast<float*>(yv) + row * ldy + col, make_float4(v[0], v[1], v[2], v[3]));
+                    else st4(reinterpret_cast<bf16_t*>(yv) + row * ldy + col, make_float4(v[0], v[1], v[2], v[3]));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     // epilogue: lane = row, register quad g of tile i = columns n0 + 32 i + 8 g + 4 h .. + 3
     const int64_t row = brow0 + wave * 32 + j;
     if (row >= m) return;
@@ -245,8 +292,8 @@ int ws_gemm_xbt_bf16(const uint16_t* x, int64_t m, int32_t k, int64_t ldx, const
 #define WS_XBT(NTV)                                                                                                        \
     do {                                                                                                                   \
         const dim3 grid((unsigned)gx, (unsigned)ws_ceil_div(n, 32 * NTV));                                                 \
-        if (out_f32) gemm_xbt_bf16_kernel<NTV, true><<<grid, 256, 0, st>>>(xb, m, k, ldx, bb, n, ldbt, y, ldy, bias, rb, ldr, act, slope, vecout); \
-        else gemm_xbt_bf16_kernel<NTV, false><<<grid, 256, 0, st>>>(xb, m, k, ldx, bb, n, ldbt, y, ldy, bias, rb, ldr, act, slope, vecout);       \
+        if (out_f32) gemm_xbt_bf16_kernel<NTV, true><<<grid, 256, 0, st>>>(xb, m, k, ldx, bb, n, ldbt, y, ldy, bias, rb, ldr, act, slope, vecout, ws_gemm_staged); \
+        else gemm_xbt_bf16_kernel<NTV, false><<<grid, 256, 0, st>>>(xb, m, k, ldx, bb, n, ldbt, y, ldy, bias, rb, ldr, act, slope, vecout, ws_gemm_staged);       \
     } while (0)
     if (n <= 32) WS_XBT(1);
     else if (n <= 64) WS_XBT(2);
