@@ -21,13 +21,15 @@ for k, n, res in ((32, 480, False), (32, 128, True), (128, 32, False), (64, 128,
     bias = torch.randn(n, device=dev)
     row = []
     ref = None
-    for st in (0, 1):
-        C.c_int.in_dll(lib, "ws_gemm_staged").value = st
+    for st in (0, 1, 2):
+        C.c_int.in_dll(lib, "ws_gemm_staged").value = min(st, 1)
+        C.c_int.in_dll(lib, "ws_gemm_thin_k").value = 64 if st == 2 else 0
         us = t(lambda: check(lib.ws_gemm_xb_epilogue(ptr(x), M, k, k, ptr(b), n, ptr(bias), ptr(r), n, 1, 0.1, ptr(y), n, current_stream())))
         row.append(us)
         if ref is None: ref = y.clone()
         same = torch.equal(ref, y)
     C.c_int.in_dll(lib, "ws_gemm_staged").value = 1
+    C.c_int.in_dll(lib, "ws_gemm_thin_k").value = 0
     mb = (M * k + M * n * (2 if res else 1)) * 4 / 1e6
     print("k=%4d n=%4d residual=%d: %s  (%.0f MB: %s TB/s)  same result: %s" % (k, n, res, "  ".join("staged=%d %6.1f us" % (i, u) for i, u in enumerate(row)), mb,
                                                              " / ".join("%.2f" % (mb / u) for u in row), same), flush=True)

@@ -1154,6 +1154,7 @@ extern "C" {
 
 // diagnostic switches of tools/gemm_lab.cpp (not part of the drop-in surface of include/weasal_hip.h)
 int ws_gemm_wave_cols = 0;  // forced wave grid of gemm_xb2 (column groups 1 / 2), 0 = automatic
+int ws_gemm_thin_k = 64;    // products with k <= this take 64-column tiles (more, lighter workgroups: they are all prologue and epilogue) instead of 128
 int ws_gemm_staged = 1;     // gemm_xb2 epilogue: 1 = the tile turned through LDS (whole 128-byte row segments per store), 0 = per-lane rows
 int ws_gemm_variant = 2;    // 1 = LDS-staged tiles (gemm_xb / gemm_xty), 2 = operands straight from global memory
 #ifdef WS_LAB_SPLIT_GEMM
@@ -1280,7 +1281,7 @@ static int gemm_xb_core(const float* x, int64_t m, int32_t k, int64_t ldx, const
         if (n <= 32) wn = 1;
         if (wn == 1) {
             if (n <= 32) WS_XB2(1, 1);
-            else if (n <= 64) WS_XB2(2, 1);
+            else if (n <= 64 || (ws_gemm_thin_k > 0 && k <= ws_gemm_thin_k)) WS_XB2(2, 1);
             else WS_XB2(4, 1);
         } else {
             if (n <= 64) WS_XB2(1, 2);
