@@ -351,3 +351,34 @@ def test_split_bf16_products_are_fp32_accurate(gpu, m, k, n):
     finally:
         sw.value = 0
     assert errw[0] < 5e-6 and errw[1] < 5e-6 and errw[1] <= 1.5 * errw[0] + 2e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n", [(1, 32, 4), (31, 64, 36), (33, 32, 100), (4099, 96, 132), (70001, 32, 480), (12000, 128, 64)])
+def test_gemm_staged_epilogue_is_bit_identical(gpu, m, k, n):
+    """the LDS-turned epilogue of gemm_xb2 (whole row segments per store) against the per-lane one: same bits for ragged
+    row / column counts, with bias + residual + LeakyReLU"""
+    import ctypes as C
+    from weasal_amd import _lib
+    from weasal_amd._lib import check, current_stream, ptr
+    lib = _lib.lib()
+    torch.manual_seed(m + n)
+    x = torch.randn(m, k, device=gpu)
+    b = torch.randn(k, n, device=gpu)
+    bias = torch.randn(n, device=gpu)
+    res = torch.randn(m, n, device=gpu)
+    outs = []
+    flag = C.c_int.in_dll(lib, "ws_gemm_staged")
+    try:
+        for staged in (0, 1):
+            flag.value = staged
+            y = torch.full((m, n), float("nan"), device=gpu)
+            check(lib.ws_gemm_xb_epilogue(ptr(x), m, k, k, ptr(b), n, ptr(bias), ptr(res), n, 1, 0.1, ptr(y), n, current_stream()))
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        flag.value = 1
+    assert bool(torch.isfinite(outs[1]).all())
+    assert torch.equal(outs[0], outs[1])
+    want = torch.nn.functional.leaky_relu((x.double() @ b.double()) + bias.double() + res.double(), 0.1)
+    assert float((outs[1].double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
