@@ -127,6 +127,17 @@ int ws_max_pool_fwd(const float* x, int64_t ns, int32_t c, const int64_t* inds, 
 int ws_max_pool_bwd(const float* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c,
                     const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns,
                     float* dx, void* stream);
+/* the same with a spatially coherent walking order (int32 permutation: the cell order of the queries' / supports' level,
+ * ws_radius_neighbors_order; NULL = index order): results do not depend on it, only the memory traffic does -- consecutive
+ * work items gather overlapping rows, and the workgroups of an XCD walk its part of the order together (pools.hip). */
+int ws_max_pool_fwd_ordered(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, float* out,
+                            int32_t* arg, const int32_t* order_q, void* stream);
+int ws_max_pool_bwd_ordered(const float* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                            const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order_s, void* stream);
+int ws_max_pool_fwd_ordered_bf16(const uint16_t* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, uint16_t* out,
+                                 int32_t* arg, const int32_t* order_q, void* stream);
+int ws_max_pool_bwd_ordered_bf16(const uint16_t* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                                 const int32_t* t_pairs, int64_t ns, uint16_t* dx, const int32_t* order_s, void* stream);
 int ws_closest_pool_fwd(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
                         float* out, void* stream);
 int ws_closest_pool_bwd(const float* dy, int64_t nq, int32_t h, int32_t c,

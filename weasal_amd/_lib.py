@@ -42,6 +42,10 @@ SIGNATURES = {
     "ws_contrast_rows_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp]),
     "ws_launch_count": (_i64, []),
+    "ws_max_pool_fwd_ordered": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ws_max_pool_bwd_ordered": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "ws_max_pool_fwd_ordered_bf16": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ws_max_pool_bwd_ordered_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ws_dropout_apply": (C.c_int, [_vp, _i64, C.c_float, C.c_uint64, _vp, _vp]),
     "ws_pyramid_build": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ws_pyramid_desc_bytes": (_i64, []),

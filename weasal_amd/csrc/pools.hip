@@ -255,43 +255,6 @@ __global__ __launch_bounds__(256) void closest_pool_bwd_kernel(const T* __restri
 }
 
 
-template <typename T>
-int max_pool_fwd_impl(const T* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
-                      T* out, int32_t* arg, void* stream)
-{
-    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
-    if (nq == 0) return WS_OK;
-    WS_REQUIRE(inds && out && (ns == 0 || x), "NULL argument");
-    hipStream_t st = (hipStream_t)stream;
-    const bool vec = (c % 4 == 0) && ws_row_aligned<T>(x) && ws_row_aligned<T>(out) && (!arg || al16p(arg));
-    if (vec && c <= 16) max_pool_fwd_vec_kernel<4, T><<<ws_grid(ws_ceil_div(nq, 16), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (vec && c <= 32) max_pool_fwd_vec_kernel<8, T><<<ws_grid(ws_ceil_div(nq, 8), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (vec && c <= 64) max_pool_fwd_vec_kernel<16, T><<<ws_grid(ws_ceil_div(nq, 4), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (vec && c <= 128) max_pool_fwd_vec_kernel<32, T><<<ws_grid(ws_ceil_div(nq, 2), 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else if (vec) max_pool_fwd_vec_kernel<64, T><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    else max_pool_fwd_kernel<T><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
-    WS_LAUNCH_CHECK();
-    return WS_OK;
-}
-
-template <typename T>
-int max_pool_bwd_impl(const T* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c,
-                      const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns, T* dx, void* stream)
-{
-    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
-    if (ns == 0) return WS_OK;
-    WS_REQUIRE(t_offsets && dx && (nq == 0 || (dy && arg && t_pairs)), "NULL argument");
-    hipStream_t st = (hipStream_t)stream;
-    const bool vec = (c % 4 == 0) && ws_row_aligned<T>(dy) && ws_row_aligned<T>(dx) && al16p(arg);
-    if (vec && c <= 32) max_pool_bwd_vec_kernel<8, T><<<ws_grid(ws_ceil_div(ns, 8), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else if (vec && c <= 64) max_pool_bwd_vec_kernel<16, T><<<ws_grid(ws_ceil_div(ns, 4), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else if (vec && c <= 128) max_pool_bwd_vec_kernel<32, T><<<ws_grid(ws_ceil_div(ns, 2), 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else if (vec) max_pool_bwd_vec_kernel<64, T><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    else max_pool_bwd_kernel<T><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
-    WS_LAUNCH_CHECK();
-    return WS_OK;
-}
-
 // workgroups per XCD of the interleaved assignment (0 = contiguous chunks; A/B switch WEASAL_POOL_INTERLEAVE).  Level-0 max-pool
 // of the DALES step (71 000 x 59 rows of 512 bytes): forward 245 -> 195 us in the step, 136 -> 97 us alone (tools/pool_lab.py)
 extern "C" int ws_pool_interleave = 256;
@@ -300,6 +263,46 @@ static inline int pool_grid(int64_t groups, int ilv)
     if (ilv <= 0) return ws_grid(groups, 4);
     const int64_t need = (groups + 31) / 32;              // never more workgroups per XCD than groups / 4 / 8
     return 8 * (int)std::max<int64_t>(1, std::min<int64_t>(ilv, need));
+}
+
+template <typename T>
+int max_pool_fwd_impl(const T* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,
+                      T* out, int32_t* arg, void* stream, const int32_t* order = nullptr)
+{
+    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
+    if (nq == 0) return WS_OK;
+    WS_REQUIRE(inds && out && (ns == 0 || x), "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && ws_row_aligned<T>(x) && ws_row_aligned<T>(out) && (!arg || al16p(arg));
+    const int ilv = order ? ws_pool_interleave : 0;
+    if (vec && c <= 16) max_pool_fwd_vec_kernel<4, T><<<pool_grid(ws_ceil_div(nq, 16), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (vec && c <= 32) max_pool_fwd_vec_kernel<8, T><<<pool_grid(ws_ceil_div(nq, 8), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (vec && c <= 64) max_pool_fwd_vec_kernel<16, T><<<pool_grid(ws_ceil_div(nq, 4), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (vec && c <= 128) max_pool_fwd_vec_kernel<32, T><<<pool_grid(ws_ceil_div(nq, 2), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (vec) max_pool_fwd_vec_kernel<64, T><<<pool_grid(nq, ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else max_pool_fwd_kernel<T><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
+}
+
+template <typename T>
+int max_pool_bwd_impl(const T* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c,
+                      const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns, T* dx, void* stream,
+                      const int32_t* order = nullptr)
+{
+    WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
+    if (ns == 0) return WS_OK;
+    WS_REQUIRE(t_offsets && dx && (nq == 0 || (dy && arg && t_pairs)), "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && ws_row_aligned<T>(dy) && ws_row_aligned<T>(dx) && al16p(arg);
+    const int ilv = order ? ws_pool_interleave : 0;
+    if (vec && c <= 32) max_pool_bwd_vec_kernel<8, T><<<pool_grid(ws_ceil_div(ns, 8), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    else if (vec && c <= 64) max_pool_bwd_vec_kernel<16, T><<<pool_grid(ws_ceil_div(ns, 4), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    else if (vec && c <= 128) max_pool_bwd_vec_kernel<32, T><<<pool_grid(ws_ceil_div(ns, 2), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    else if (vec) max_pool_bwd_vec_kernel<64, T><<<pool_grid(ns, ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    else max_pool_bwd_kernel<T><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
+    WS_LAUNCH_CHECK();
+    return WS_OK;
 }
 
 // the block calls' private form: arg-max record in bytes (h <= 255, c % 4 == 0, aligned rows: the caller checks)
@@ -369,6 +372,32 @@ int ws_max_pool_bwd(const float* dy, const int32_t* arg, int64_t nq, int32_t h, 
                     const int32_t* t_offsets, const int32_t* t_pairs, int64_t ns, float* dx, void* stream)
 {
     return max_pool_bwd_impl<float>(dy, arg, nq, h, c, t_offsets, t_pairs, ns, dx, stream);
+}
+
+int ws_max_pool_fwd_ordered(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, float* out, int32_t* arg,
+                            const int32_t* order_q, void* stream)
+{
+    return max_pool_fwd_impl<float>(x, ns, c, inds, nq, h, out, arg, stream, order_q);
+}
+
+int ws_max_pool_bwd_ordered(const float* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                            const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order_s, void* stream)
+{
+    return max_pool_bwd_impl<float>(dy, arg, nq, h, c, t_offsets, t_pairs, ns, dx, stream, order_s);
+}
+
+int ws_max_pool_fwd_ordered_bf16(const uint16_t* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, uint16_t* out,
+                                 int32_t* arg, const int32_t* order_q, void* stream)
+{
+    return max_pool_fwd_impl<bf16_t>(reinterpret_cast<const bf16_t*>(x), ns, c, inds, nq, h, reinterpret_cast<bf16_t*>(out), arg, stream,
+                                     order_q);
+}
+
+int ws_max_pool_bwd_ordered_bf16(const uint16_t* dy, const int32_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
+                                 const int32_t* t_pairs, int64_t ns, uint16_t* dx, const int32_t* order_s, void* stream)
+{
+    return max_pool_bwd_impl<bf16_t>(reinterpret_cast<const bf16_t*>(dy), arg, nq, h, c, t_offsets, t_pairs, ns,
+                                     reinterpret_cast<bf16_t*>(dx), stream, order_s);
 }
 
 int ws_closest_pool_fwd(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h,

@@ -163,6 +163,18 @@ class SearchGrid:
         return (self.blob, self.key_last, self.overflow)
 
 
+_pool_orders = {}
+
+
+def set_pool_orders(triples):
+    """[(pooling index matrix [Nq, H], cell order of its queries or None, cell order of its supports or None)]: scheduling hints
+    of ops.max_pool for the batch about to be trained on (PyramidBatch.activate); results never depend on them"""
+    _pool_orders.clear()
+    for inds, oq, osup in triples:
+        if isinstance(inds, torch.Tensor) and inds.dim() == 2 and inds.shape[0] > 0:
+            _pool_orders[(inds.data_ptr(), tuple(inds.shape))] = (oq, osup)
+
+
 def set_search_grids(pairs):
     """install the (index matrix, SearchGrid) pairs of the batch about to be trained on (PyramidBatch.activate)"""
     _grids.clear()
@@ -774,9 +786,15 @@ class _MaxPool(torch.autograd.Function):
         nq, h = inds.shape
         out = torch.empty((nq, c), dtype=x.dtype, device=x.device)
         arg = torch.empty((nq, c), dtype=torch.int32, device=x.device)
-        check(_by_dtype(lib, "ws_max_pool_fwd", x)(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), ptr(arg), current_stream()))
+        oq, osup = _pool_orders.get((inds.data_ptr(), tuple(inds.shape)), (None, None))      # scheduling hints (PyramidBatch.activate)
+        if oq is not None and oq.numel() != nq:
+            oq = None
+        if osup is not None and osup.numel() != ns:
+            osup = None
+        check(_by_dtype(lib, "ws_max_pool_fwd_ordered", x)(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), ptr(arg), ptr(oq), current_stream()))
         ctx.save_for_backward(arg, inds)
         ctx.ns = ns
+        ctx.order_s = osup
         return out
 
     @staticmethod
@@ -788,8 +806,8 @@ class _MaxPool(torch.autograd.Function):
         table = transposed_table(inds, ctx.ns)
         dx = torch.empty((ctx.ns, c), dtype=dy.dtype, device=dy.device)
         dy = dy.contiguous()
-        check(_by_dtype(lib, "ws_max_pool_bwd", dy)(ptr(dy), ptr(arg), nq, h, c, ptr(table.offsets), ptr(table.pairs), ctx.ns,
-                                  ptr(dx), current_stream()))
+        check(_by_dtype(lib, "ws_max_pool_bwd_ordered", dy)(ptr(dy), ptr(arg), nq, h, c, ptr(table.offsets), ptr(table.pairs), ctx.ns,
+                                                            ptr(dx), ptr(ctx.order_s), current_stream()))
         return dx, None
 
 

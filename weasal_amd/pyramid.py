@@ -468,6 +468,9 @@ class PyramidBatch:
                         t.record_stream(stream)
                 self.ready = None
             ops.set_point_orders(self.point_orders)
+            by_points = {p.data_ptr(): o for p, o in self.point_orders}
+            ops.set_pool_orders([(self.pools[l], by_points.get(self.points[l + 1].data_ptr()), by_points.get(self.points[l].data_ptr()))
+                                 for l in range(len(self.points) - 1)])
             ops.set_sorted_rows(self.search_radii)     # rows as the radius search wrote them: sorted by distance
             ops.set_search_grids(self.search_grids)
             ops.clear_table_cache()              # tables belong to one batch
