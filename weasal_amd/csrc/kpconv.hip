@@ -15,6 +15,7 @@
 #include "ws_bf16.h"
 
 extern "C" int ws_kpconv_table_interleave;
+extern "C" int ws_kpconv_gridw_interleave;
 extern "C" int ws_kpconv_grid_interleave;
 namespace {
 
@@ -1857,10 +1858,10 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_x_gridw_kernel(
         cut2 = R * R;
     }
 
-    int64_t ibeg, iend;
-    ws_block_range(ns, ibeg, iend);
+    int64_t item0, istep, iend;
+    ws_wave_items(ns, order ? g.ilv : 0, wave, item0, istep, iend);
     CloudGrid gr = grids[0];
-    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+    for (int64_t item = item0; item < iend; item += istep) {
         const int64_t s = order ? (int64_t)order[item] : item;
         if (s < gr.s_base || s >= gr.s_base + gr.s_len) {
             int b = 0;
@@ -2118,6 +2119,7 @@ int ws_kpconv_gs = 0;
 extern "C" int ws_kpconv_grid_rows;       // diagnostics: 0 = K4G always walks the cell grid (WEASAL_K4G_ROWS=0)
 int ws_kpconv_grid_rows = 1;
 extern "C" int ws_kpconv_grid_sorted;     // 1: ws_kpconv_gather_bwd_x_grid sums the incoming pairs in index order (the pair order of
+extern "C" int ws_kpconv_gridw_interleave = 512;    // the same for the wide-row K4G of config 5 (WEASAL_K4GW_INTERLEAVE)
 extern "C" int ws_kpconv_table_interleave = 0;    // the same for the transposed-table K4 (WEASAL_K4_INTERLEAVE)
 extern "C" int ws_kpconv_grid_interleave = 512;   // lab: workgroups per XCD of the interleaved assignment (WEASAL_K4G_INTERLEAVE)
 int ws_kpconv_grid_sorted = 0;            //    the transposed table: bit-identical to ws_kpconv_gather_bwd_x); 0: in grid-walk order
@@ -2443,7 +2445,8 @@ int gather_bwd_x_gridw_impl(const float* s_pts, int64_t ns, const void* grid_blo
     const float4* sorted = (const float4*)(base + ws_grid_blob_sorted_off(nb, cells));
     const float r2 = radius * radius;
     const unsigned long long* kl = reinterpret_cast<const unsigned long long*>(key_last);
-    const int grid = ws_grid(ns, 4);
+    g.ilv = order ? ws_kpconv_gridw_interleave : 0;
+    const int grid = g.ilv > 0 ? 8 * (int)std::max<int64_t>(1, std::min<int64_t>(g.ilv, ws_ceil_div(ns, 32))) : ws_grid(ns, 4);
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(dwf) && ws_row_aligned<T>(dx);
     WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
 #define WS_GW3(G, MODEV, VECV, NCHV)                                                                                  \
