@@ -16,6 +16,7 @@
 
 extern "C" int ws_kpconv_table_interleave;
 extern "C" int ws_kpconv_gridw_interleave;
+extern "C" int ws_kpconv_k6_interleave;
 extern "C" int ws_kpconv_grid_interleave;
 namespace {
 
@@ -1350,7 +1351,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_def_kernel(
     const float* __restrict__ q_pts, int64_t nq, const float* __restrict__ s_pts, int64_t ns,
     const int64_t* __restrict__ inds, int h, const T* __restrict__ x, int ci, const T* __restrict__ dwf,
     const float4* __restrict__ kp4, const float* __restrict__ d_min_d2, float extent, float4* __restrict__ d_kp4,
-    const int32_t* __restrict__ order)
+    const int32_t* __restrict__ order, int ilv)
 {
     constexpr int K = 15;
     constexpr int CB = 4 * CK;                                   // channels per pass of the product
@@ -1360,9 +1361,9 @@ __global__ __launch_bounds__(256) void kpconv_gather_bwd_geom_def_kernel(
     const int j = lane & 15, g = lane >> 4;                       // (= i, kk of the A / B operands)
     float4* nb = nb_all[wave];
     const float inv_extent = 1.0f / extent;
-    int64_t ibeg, iend;
-    ws_block_range(nq, ibeg, iend);
-    for (int64_t item = ibeg + wave; item < iend; item += 4) {
+    int64_t item0, istep, iend;
+    ws_wave_items(nq, order ? ilv : 0, wave, item0, istep, iend);
+    for (int64_t item = item0; item < iend; item += istep) {
         const int64_t q = order ? (int64_t)order[item] : item;
         float4 kq[4];
         float cm[4];
@@ -2119,6 +2120,7 @@ int ws_kpconv_gs = 0;
 extern "C" int ws_kpconv_grid_rows;       // diagnostics: 0 = K4G always walks the cell grid (WEASAL_K4G_ROWS=0)
 int ws_kpconv_grid_rows = 1;
 extern "C" int ws_kpconv_grid_sorted;     // 1: ws_kpconv_gather_bwd_x_grid sums the incoming pairs in index order (the pair order of
+extern "C" int ws_kpconv_k6_interleave = 0;       // the same for the geometry backward on the matrix core (WEASAL_K6_INTERLEAVE)
 extern "C" int ws_kpconv_gridw_interleave = 512;    // the same for the wide-row K4G of config 5 (WEASAL_K4GW_INTERLEAVE)
 extern "C" int ws_kpconv_table_interleave = 0;    // the same for the transposed-table K4 (WEASAL_K4_INTERLEAVE)
 extern "C" int ws_kpconv_grid_interleave = 512;   // lab: workgroups per XCD of the interleaved assignment (WEASAL_K4G_INTERLEAVE)
@@ -2492,15 +2494,16 @@ int gather_bwd_geom_def_impl(const float* q_pts, int64_t nq, const float* s_pts,
     if (ci % 16 != 0 || !aligned16(x) || !aligned16(dwf))
         return ws_fail(WS_ERR_UNSUPPORTED, "geometry backward on the matrix core needs ci %% 16 == 0 and 16-byte aligned rows (ci=%d)", ci);
     hipStream_t st = (hipStream_t)stream;
-    const int grid = ws_grid(nq, 4);
+    const int ilv = order ? ws_kpconv_k6_interleave : 0;
+    const int grid = ilv > 0 ? 8 * (int)std::max<int64_t>(1, std::min<int64_t>(ilv, ws_ceil_div(nq, 32))) : ws_grid(nq, 4);
 #define WS_K6(CKV, AREGV)                                                                                                 \
     do {                                                                                                                  \
         if (rows_sorted)                                                                                                  \
             kpconv_gather_bwd_geom_def_kernel<CKV, AREGV, T, true><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf, kp4, \
-                                                                                         d_min_d2, extent, d_kp4, order); \
+                                                                                         d_min_d2, extent, d_kp4, order, ilv); \
         else                                                                                                              \
             kpconv_gather_bwd_geom_def_kernel<CKV, AREGV, T, false><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, dwf, kp4, \
-                                                                                          d_min_d2, extent, d_kp4, order); \
+                                                                                          d_min_d2, extent, d_kp4, order, ilv); \
     } while (0)
     if (ci == 16) WS_K6(4, true);
     else if (ci == 32) WS_K6(8, true);
