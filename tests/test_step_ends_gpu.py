@@ -171,3 +171,41 @@ def test_dropout_kernel_mask_statistics_and_backward():
     a = ops.dropout(x, 0.5)
     torch.manual_seed(3)
     assert torch.equal(ops.dropout(x, 0.5), a)
+
+
+@pytest.mark.gpu
+def test_training_steps_are_bit_reproducible():
+    """three Vaihingen training steps (one-call pyramid with limits, grid-walk backward, split-K products, fused update), run
+    twice from the same seeds in one process: identical index matrices, logits, losses and final weights -- no kernel of the
+    step sums in an order that depends on scheduling (the search grid's cells are filled through an atomic cursor and then
+    put in index order: csrc/neighbors.hip, nb_cell_rank_kernel)"""
+    from weasal_amd import config as wcfg, pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    from weasal_amd.trainer import make_optimizer, train_step
+    dev = torch.device("cuda:0")
+
+    def run():
+        cfg = wcfg.Vaihingen3DPLConfig()
+        np.random.seed(1)
+        torch.manual_seed(1)
+        net = KPFCNN(cfg, np.arange(9), []).to(dev).train()
+        opt = make_optimizer(net, cfg)
+        wl = synthetic.WORKLOADS["vaihingen"]
+        seen = []
+        for step in range(3):
+            pts, feats, labels, lens = synthetic.make_inputs(40 + step, 2, wl["points"], wl["radius"], cfg.in_features_dim)
+            np.random.seed(step)
+            batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev),
+                                        torch.from_numpy(labels).to(dev), lens, wl["limits"])
+            loss, out = train_step(net, opt, batch, cfg, epoch=0)          # dropout and the contrastive term included
+            seen.append((float(loss.detach()), out.detach().clone(), [m.clone() for m in batch.neighbors + batch.pools]))
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in net.state_dict().items()}, seen
+
+    a, sa = run()
+    b, sb = run()
+    for (la, oa, ma), (lb, ob, mb) in zip(sa, sb):
+        assert la == lb and torch.equal(oa, ob)
+        assert all(torch.equal(x, y) for x, y in zip(ma, mb))
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
