@@ -428,21 +428,29 @@ class KPFCNN_mprm(nn.Module):
         """overlap-region loss (architectures.py:735-784): the four class-activation maps are averaged over every
         labelled sub-region of every sphere and compared with the sub-region's weak labels"""
         dev = cam[0].device
-        cam_all = torch.stack(cam, dim=0)
-        averaged, all_lbs = [], []
+        cam_all = torch.stack(cam, dim=0)                              # [4, N, C]
+        # The reference averages region by region (one index upload and one gather per region, :752-768).  Same means as ONE
+        # product: A [R, N] holds 1 / |region| at the region's points (built on the host from the host-side index lists, one
+        # upload), averaged[r, k, :] = A[r, :] @ cam_k -- no per-region copies, no device-to-host reads.
+        lens_host = np.asarray(batch_lengths.cpu() if isinstance(batch_lengths, torch.Tensor) else batch_lengths).astype(np.int64)
+        n_total = int(cam_all.shape[1])
+        rows, all_lbs = [], []
         start = 0
         for ri in range(len(regions_all)):
-            n = int(batch_lengths[ri])
+            n = int(lens_host[ri])
             if len(regions_all[ri]) > 0:
-                logits = cam_all[:, start:start + n, :]
                 all_lbs.append(np.stack(regions_lb[ri]).astype('float32'))
                 for region in regions_all[ri]:
-                    idx = torch.from_numpy(np.asarray(region).astype('int64')).to(dev)
-                    assert logits.shape[1] >= int(idx.max()), 'logits problem'
-                    averaged.append(torch.mean(logits[:, idx, :], dim=1))
+                    idx = np.asarray(region).astype('int64')
+                    assert n >= int(idx.max()), 'logits problem'
+                    w = np.zeros(n_total, dtype=np.float32)
+                    np.add.at(w, idx + start, np.float32(1.0 / len(idx)))
+                    rows.append(w)
             start += n
         all_lbs = torch.from_numpy(np.vstack(all_lbs)).to(dev)
-        averaged = torch.stack(averaged)
+        A = torch.from_numpy(np.stack(rows)).to(dev)                   # [R, N]
+        k, _, c = cam_all.shape
+        averaged = (A @ cam_all.permute(1, 0, 2).reshape(n_total, k * c)).reshape(A.shape[0], k, c)
         self.output_loss = 0
         for ii in range(averaged.shape[1]):
             self.output_loss = self.output_loss + self.criterion_multi(averaged[:, ii, :], all_lbs)

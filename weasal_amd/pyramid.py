@@ -148,6 +148,7 @@ def segmentation_inputs(config, stacked_points, stacked_features, labels, stack_
             if 0 < grid.max_count <= grid.cap:
                 search_grids.append((final[slot], grid))
     # the per-layer lengths go to the device in ONE copy (views of it are handed out)
+    _last_host_lengths.value = [np.ascontiguousarray(a) for a in input_lengths]
     sizes = [len(a) for a in input_lengths]
     all_lens = torch.from_numpy(np.concatenate(input_lengths).astype(np.int32)).to(dev)
     input_lengths = list(torch.split(all_lens, sizes))
@@ -367,7 +368,15 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
                     if tb is not None:
                         col0.append((upsamples[l], n[l + 1], tb))
         tables["full"], tables["col0"] = full, col0
+    _last_host_lengths.value = lens_host
     return points + neighbors + pools + upsamples + [lens_all[l] for l in range(L)] + [stacked_features, labels]
+
+
+class _TLS(__import__("threading").local):
+    value = None
+
+
+_last_host_lengths = _TLS()    # host copy of the per-level lengths of the pyramid this thread built last (build_batch picks it up)
 
 
 ACTIVATE_STALLS = None       # set to a list to collect (event, event) pairs around the hand-over wait (bench.py --stall-diag)
@@ -392,6 +401,7 @@ class PyramidBatch:
         if extra == 7:
             self.scales, self.rots, self.cloud_inds, self.center_inds, self.input_inds = input_list[5 * L + 2:5 * L + 7]
         self.point_orders = list(point_orders)   # [(points tensor, cell-order permutation)]: scheduling hints
+        self.lengths_host = None                 # per-level lengths as host arrays (set by build_batch)
         self.search_grids = []                   # [(index matrix, ops.SearchGrid)]: table-free backward of self-query layers
         self.search_radii = []                   # [(index matrix, radius of the search that wrote it)]: rows sorted by distance
         self.tables = []                         # pre-built transposed tables [(inds, ns, table)] (build_tables)
@@ -493,6 +503,8 @@ def build_batch(config, points, features, labels, lengths, neighborhood_limits=(
     batch = PyramidBatch(li, orders)
     batch.search_grids = grids
     batch.search_radii = radii
+    batch.lengths_host = _last_host_lengths.value        # numpy int32 [B] per level: host-side consumers need no read-back
+    _last_host_lengths.value = None
     if tables is not None:
         batch.tables, batch.col0_tables = tables["full"], tables["col0"]
     elif with_tables and points.is_cuda:

@@ -118,7 +118,8 @@ def train_step_weak(net, optimizer, batch, config, grad_sync=None):
     optimizer.zero_grad(set_to_none=grad_sync is None)
     logits, class_logits, cam = net(batch, config)
     if config.loss_type == 'region_mprm_loss':
-        loss = net.region_mprm_loss(cam, batch.region, batch.region_lb, batch.lengths[0])
+        lens0 = batch.lengths_host[0] if getattr(batch, 'lengths_host', None) is not None else batch.lengths[0]
+        loss = net.region_mprm_loss(cam, batch.region, batch.region_lb, lens0)       # (host lengths: no device read-back)
     else:
         loss = net.class_logits_loss(class_logits, batch.cloud_lb)
     if grad_sync is not None and hasattr(grad_sync, "arm"):
