@@ -56,6 +56,13 @@ def max_pool(x, inds):
     return ops.max_pool(x, inds)
 
 
+def _layer_lengths(batch, layer_ind):
+    """sphere sizes of a level for HOST-side loops: the host copy the pyramid builder kept (PyramidBatch.lengths_host) when
+    there is one -- reading the device vector back would wait for everything queued on the stream, once per block"""
+    lh = getattr(batch, "lengths_host", None)
+    return lh[layer_ind] if lh is not None else batch.lengths[layer_ind]
+
+
 def global_average(x, batch_lengths):
     """per-cloud mean of the stacked features (blocks.py:114-134)"""
     lengths = [int(v) for v in batch_lengths]
@@ -369,7 +376,7 @@ class GlobalAverageBlock(nn.Module):
         super(GlobalAverageBlock, self).__init__()
 
     def forward(self, x, batch):
-        return global_average(x, batch.lengths[-1])
+        return global_average(x, _layer_lengths(batch, -1))
 
 
 class NearestUpsampleBlock(nn.Module):
@@ -437,7 +444,7 @@ class spatial_att(nn.Module):
         features = self.simple1(features, batch)
         q, k, v = self.unary1(features), self.unary2(features), self.unary3(features)
         outs, outs_n = [], []
-        for a, b in _per_cloud(batch.lengths[self.layer_ind]):
+        for a, b in _per_cloud(_layer_lengths(batch, self.layer_ind)):
             att = torch.matmul(self.softmax(torch.matmul(q[a:b], k[a:b].T)), v[a:b])
             outs.append(att)
             outs_n.append(att / float(b - a))
@@ -469,7 +476,7 @@ class channel_att(nn.Module):
         features = self.simple1(features, batch)
         x1, x2 = self.unary1(features), self.unary2(features)
         outs = []
-        for a, b in _per_cloud(batch.lengths[self.layer_ind]):
+        for a, b in _per_cloud(_layer_lengths(batch, self.layer_ind)):
             energy = torch.matmul(x1[a:b].T, x2[a:b])
             energy_new = torch.max(energy, -1, keepdim=True)[0].expand_as(energy) - energy
             outs.append(torch.matmul(features[a:b], self.softmax(energy_new)))
@@ -518,7 +525,7 @@ class global_average_block(nn.Module):
         self.out_dim = out_dim
 
     def forward(self, features, batch):
-        return global_average(features, batch.lengths[self.layer_ind])
+        return global_average(features, _layer_lengths(batch, self.layer_ind))
 
 
 class ele_att(nn.Module):
@@ -541,7 +548,7 @@ class ele_att(nn.Module):
 
     def forward(self, features, h, batch):
         # the two projections run once on all spheres (UnaryBlock is row-wise, so this equals the per-sphere calls)
-        spans = _per_cloud(batch.lengths[self.layer_ind])
+        spans = _per_cloud(_layer_lengths(batch, self.layer_ind))
         if h.shape[0] > 0:
             centre_z = torch.cat([batch.center_pts[ii][-1].to(h.dtype).expand(b - a, 1) for ii, (a, b) in enumerate(spans)], 0)
         else:
