@@ -219,6 +219,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nearest-upsample", type=int, default=0,
+                    help="1: opt-in nearest-only upsampling searches (the [N, 1] matrices KP-FCNN actually reads; the reference's "
+                         "batch carries the full rows, which stays the default and the contract line)")
     ap.add_argument("--workload", default="dales", choices=["dales", "vaihingen", "dales_deform", "dales_deform_f32", "vaihingen_wl"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-batches", type=int, default=4)
@@ -257,6 +260,8 @@ def main():
     wl = synthetic.WORKLOADS[args.workload]
     cfg_cls = getattr(wcfg, wl["config"])
     cfg = cfg_cls()
+    if args.nearest_upsample:
+        cfg.nearest_upsample_only = True
     np.random.seed(1234 + rank)
     torch.manual_seed(1234)            # same initial replica everywhere
     weak = getattr(cfg, "model_name", "") == "KPFCNN_mprm"          # BASELINE config 1: the weak-label step
@@ -411,7 +416,9 @@ def main():
                           + (", step = GPU pyramid + fwd + loss + bwd" + exch + " + SGD" if args.mode == "train" else
                              ", step = GPU pyramid + forward under no_grad (the voting test's pass)")
                           + ("; contrast_loss term included (trainer_PseudoLabel.py:204-208)" if args.contrast else "; contrast_loss term (trainer_PseudoLabel.py:204-208) left out (--contrast 0)")
-                          + ("; pyramid of the next batch overlapped on a second stream" if args.prefetch else ""),
+                          + ("; pyramid of the next batch overlapped on a second stream" if args.prefetch else "")
+                          + ("; OPT-IN nearest-only upsampling searches ([N, 1] matrices instead of the reference's full rows)"
+                             if pyramid.nearest_upsample_only(cfg) else ""),
                           "points_per_step_per_gpu": n_points, "parallelism": "dp%d" % world,
                           "dist_backend": backend,
                           # what the process group itself says (not the flag): ranks that took part in the exchange

@@ -224,6 +224,13 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws,
                                      const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
                                      float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
                                      int32_t* d_max_count, void* stream);
+/* Nearest neighbour only (opt-in): out [nq] = column 0 of the row ws_radius_neighbors_search_async would write -- the support
+ * with the smallest (distance, index) inside `radius`, or ns -- without building and sorting the row.  For the UPSAMPLING
+ * searches of the pyramid, of which KP-FCNN reads the first column only (models/blocks.py:92-111); *d_any (device) becomes
+ * 1 if any query found a support, else 0.  Same grid reuse (ws_radius_neighbors_reuse_grid) as the full search. */
+int ws_radius_neighbors_nearest_async(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
+                                      int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                                      float radius, int32_t* out_i32, int64_t* out_i64, int32_t* d_any, void* stream);
 /* supports of the last plan/search in cell order (device int32 [ns], a permutation): a spatially
  * coherent scheduling order for the kernels that take `order`. */
 int ws_radius_neighbors_order(const ws_neighbors_ws* ws, int32_t* out_order, void* stream);
@@ -349,7 +356,7 @@ typedef struct ws_pyramid_desc {
     int32_t conv_on[WS_PYRAMID_MAX_LEVELS], pool_on[WS_PYRAMID_MAX_LEVELS];
     float r_conv[WS_PYRAMID_MAX_LEVELS], r_pool[WS_PYRAMID_MAX_LEVELS], r_up[WS_PYRAMID_MAX_LEVELS], dl[WS_PYRAMID_MAX_LEVELS];
     int32_t limit[WS_PYRAMID_MAX_LEVELS + 1];
-    int32_t reserved1;
+    int32_t nearest_up;                  /* 1: upsampling matrices hold the nearest support only, [n, 1] (ws_radius_neighbors_nearest_async) */
     /* in (level 0) / out (levels >= 1) */
     int32_t lens[WS_PYRAMID_MAX_LEVELS][WS_PYRAMID_MAX_BATCH];
     /* out */

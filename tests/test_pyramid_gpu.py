@@ -464,3 +464,49 @@ def test_one_call_pyramid_errors_and_fallbacks():
             pyramid.build_batch(cfg, P, F, L, lens_bad, wl["limits"])       # an empty element next to full ones is legal
         finally:
             pyramid.NATIVE_PYRAMID = True
+
+
+@pytest.mark.gpu
+def test_nearest_only_upsampling_is_column_zero_and_trains_identically():
+    """opt-in nearest-only upsampling search (ws_radius_neighbors_nearest_async; config.nearest_upsample_only): the [N, 1]
+    matrices equal column 0 of the full rows bit for bit (same (distance, index) order, ns where the radius is empty), every
+    other tensor of the batch is unchanged, and a training step gives bit-identical logits, loss and weights -- the network
+    reads nothing else of an upsampling matrix"""
+    import copy
+    from weasal_amd import config as wcfg, pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    from weasal_amd.trainer import make_optimizer, train_step
+    dev = torch.device("cuda:0")
+    for name, cfgn, spheres, points, scale in (("vaihingen", "Vaihingen3DPLConfig", 3, 2500, 1.0), ("dales_deform", "DALESDeformConfig", 2, 6000, 0.45)):
+        wl = synthetic.WORKLOADS[name]
+        cfg = getattr(wcfg, cfgn)()
+        cfg.dropout = 0.0
+        pts, feats, labels, lens = synthetic.make_inputs(8, spheres, points, wl["radius"] * scale, cfg.in_features_dim)
+        args = (torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev), lens, wl["limits"])
+        np.random.seed(4)
+        full = pyramid.build_batch(cfg, *args)
+        cfg_n = copy.copy(cfg)
+        cfg_n.nearest_upsample_only = True
+        np.random.seed(4)
+        near = pyramid.build_batch(cfg_n, *args)
+        L = len(full.points)
+        for l in range(L):
+            assert torch.equal(full.points[l], near.points[l]) and torch.equal(full.neighbors[l], near.neighbors[l])
+            assert torch.equal(full.pools[l], near.pools[l])
+            if l + 1 < L:
+                assert near.upsamples[l].shape == (full.points[l].shape[0], 1)
+                assert torch.equal(near.upsamples[l][:, 0], full.upsamples[l][:, 0])
+        if cfgn == "DALESDeformConfig":
+            continue                                   # (the bf16 step is compared on the f32 network below only)
+        outs = []
+        for batch in (full, near):
+            np.random.seed(5)
+            torch.manual_seed(5)
+            net = KPFCNN(cfg, np.arange(9), []).to(dev).train()
+            opt = make_optimizer(net, cfg)
+            loss, out = train_step(net, opt, batch, cfg)
+            torch.cuda.synchronize()
+            outs.append((float(loss.detach()), out.detach().clone(), {k: v.detach().clone() for k, v in net.state_dict().items()}))
+        assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+        for k in outs[0][2]:
+            assert torch.equal(outs[0][2][k], outs[1][2][k]), k

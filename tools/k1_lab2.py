@@ -13,15 +13,15 @@ np.random.seed(0)
 batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev), lens, wl["limits"])
 lib = _lib.lib()
 L = len(batch.points)
-r0 = cfg.first_subsampling_dl * cfg.conv_radius
+sched = pyramid._schedule(cfg, wl["limits"])          # the radii the pyramid really searches with (deformable levels: 2 r)
 searches = []
 for l in range(L):
     P = batch.points[l]; ll = batch.lengths[l].cpu().numpy().astype(np.int32)
-    searches.append(("conv%d" % l, P, P, ll, ll, r0 * 2 ** l, wl["limits"][l]))
+    searches.append(("conv%d" % l, P, P, ll, ll, sched[l]["r_conv"], wl["limits"][l]))
     if l + 1 < L:
         Q = batch.points[l + 1]; ql = batch.lengths[l + 1].cpu().numpy().astype(np.int32)
-        searches.append(("pool%d" % l, Q, P, ql, ll, r0 * 2 ** l, wl["limits"][l]))
-        searches.append(("up%d" % l, P, Q, ll, ql, 2 * r0 * 2 ** l, wl["limits"][l + 1]))
+        searches.append(("pool%d" % l, Q, P, ql, ll, sched[l]["r_pool"], wl["limits"][l]))
+        searches.append(("up%d" % l, P, Q, ll, ql, sched[l]["r_up"], wl["limits"][l + 1]))
 def sw(name, v):
     C.c_int.in_dll(lib, name).value = v
 ws = ops._ws.neighbors(dev)

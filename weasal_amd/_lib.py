@@ -42,6 +42,7 @@ SIGNATURES = {
     "ws_contrast_rows_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp]),
     "ws_launch_count": (_i64, []),
+    "ws_radius_neighbors_nearest_async": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i32, C.c_float, _vp, _vp, _vp, _vp]),
     "ws_max_pool_fwd_ordered": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "ws_max_pool_bwd_ordered": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "ws_max_pool_fwd_ordered_bf16": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),

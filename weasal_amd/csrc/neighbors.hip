@@ -438,6 +438,79 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
     if (max_count) nb_publish_max(max_count, local_max, lane);
 }
 
+// Nearest neighbour only: column 0 of the row the full search would write (the smallest (d2, index) key inside the radius),
+// or ns.  What KP-FCNN reads of an UPSAMPLING matrix (closest_pool / nearest upsampling: models/blocks.py:92-111 take
+// inds[:, 0]) -- without the compaction and the sort of a 60 .. 550-entry row.  Opt-in (ws_radius_neighbors_nearest_async).
+template <typename OutT>
+__global__ __launch_bounds__(256) void nb_nearest_kernel(const float* __restrict__ queries, int64_t nq,
+                                                          const CloudGrid* __restrict__ grids, int nb,
+                                                          const int32_t* __restrict__ cell_start,
+                                                          const float4* __restrict__ sorted, float r2, int64_t ns,
+                                                          const int32_t* __restrict__ qorder, OutT* __restrict__ out,
+                                                          int32_t* __restrict__ any_hit)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int64_t ibeg, iend;
+    ws_block_range(nq, ibeg, iend);
+    int b = 0;
+    CloudGrid g = grids[0];
+    int found_any = 0;
+    for (int64_t it = ibeg + wave; it < iend; it += 4) {
+        const int64_t q = qorder ? (int64_t)qorder[it] : it;
+        if (q < g.q_base || q >= g.q_base + g.q_len) {
+            b = find_cloud_q(grids, nb, q);
+            g = grids[b];
+        }
+        const float qx = queries[3 * q], qy = queries[3 * q + 1], qz = queries[3 * q + 2];
+        unsigned long long best = ~0ull;
+        if (g.s_len > 0) {
+            const int cx = cell_coord(qx, g.lo[0], g.inv_cell);
+            const int cy = cell_coord(qy, g.lo[1], g.inv_cell);
+            const int cz = cell_coord(qz, g.lo[2], g.inv_cell);
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            int rb[9], re[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+                const bool ok = x0 <= x1 && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+                const int row = g.cell_base + ((ok ? z : 0) * g.ny + (ok ? y : 0)) * g.nx;
+                rb[r] = ok ? cell_start[row + x0] : 0;
+                re[r] = ok ? cell_start[row + x1 + 1] : 0;
+            }
+            float4 c[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int p = rb[r] + lane;
+                c[r] = sorted[p < re[r] ? p : 0];
+            }
+            auto take = [&](const float4& cc, bool active) {
+                const float d2 = ref_d2(qx, qy, qz, cc);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(cc.w);
+                if (active && d2 < r2 && key < best) best = key;
+            };
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                take(c[r], rb[r] + lane < re[r]);
+                for (int p0 = rb[r] + 64; p0 < re[r]; p0 += 64) {
+                    const int p = p0 + lane;
+                    float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p < re[r]) cc = sorted[p];
+                    take(cc, p < re[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)best, o, 64), hi = __shfl_xor((unsigned)(best >> 32), o, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            best = other < best ? other : best;
+        }
+        if (lane == 0) out[q] = best != ~0ull ? (OutT)(unsigned)(best & 0xffffffffull) : (OutT)ns;
+        found_any |= best != ~0ull ? 1 : 0;
+    }
+    if (any_hit && lane == 0 && found_any) nb_publish_max(any_hit, 1, 0);
+}
+
 // Rows of 129 .. 1024 neighbours: the deformable radius of BASELINE config 5 (datasets/common.py:500-502: every level is
 // searched at 2 r, about 8 x the neighbours; calibrated limits 422 / 519 / 472).  Same candidate walk as nb_fill128; what
 // changes is the sort.  Rank by counting is quadratic (500 keys: 250 000 comparisons per query) and the bitonic network
@@ -912,6 +985,30 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, 
     if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st))) return rc;   // max-count word cleared by nb_prepare
     WS_HIP(hipMemcpyAsync(d_max_count, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     ws->max_count_host = cap;   // unknown on the host; rows beyond the slab are reported through d_max_count
+    return WS_OK;
+}
+
+int ws_radius_neighbors_nearest_async(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
+                                      int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
+                                      float radius, int32_t* out_i32, int64_t* out_i64, int32_t* d_any, void* stream)
+{
+    KeyLastGuard guard{ws};
+    WS_REQUIRE(d_any, "NULL argument");
+    WS_REQUIRE((out_i32 != nullptr) != (out_i64 != nullptr), "exactly one of out_i32 / out_i64 must be given");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = nb_prepare(ws, queries, nq, supports, ns, h_q_lens, h_s_lens, nb, radius, st);
+    if (rc) { if (ws) ws->nq = 0; return rc; }
+    const int grid = ws_grid(ws->nq, 4);
+    const int32_t* qo = ws->self_query ? ws->order.p : nullptr;
+    if (out_i32)
+        nb_nearest_kernel<int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p, ws->sorted.p, ws->r2,
+                                                         ws->ns, qo, out_i32, ws->max_count_word);
+    else
+        nb_nearest_kernel<int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p, ws->sorted.p, ws->r2,
+                                                         ws->ns, qo, out_i64, ws->max_count_word);
+    WS_LAUNCH_CHECK();
+    WS_HIP(hipMemcpyAsync(d_any, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    ws->max_count_host = 1;
     return WS_OK;
 }
 

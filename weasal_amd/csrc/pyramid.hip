@@ -120,7 +120,7 @@ extern "C" int ws_pyramid_build(ws_neighbors_ws* nws, ws_subsample_ws* sws, ws_p
             d->off_blob[l] = A.take(d->blob_bytes[l]);
         }
         d->off_pools[l] = d->pool_on[l] ? A.take(d->n[l + 1] * d->limit[l] * 8) : -1;
-        d->off_upsamples[l] = d->pool_on[l] ? A.take(n * d->limit[l + 1] * 8) : -1;
+        d->off_upsamples[l] = d->pool_on[l] ? A.take(n * (d->nearest_up ? 1 : d->limit[l + 1]) * 8) : -1;
     }
     for (int l = 0; l < L; ++l)
         for (int k = 0; k < 3; ++k) { d->off_toffsets[3 * l + k] = -1; d->off_tpairs[3 * l + k] = -1; d->final_width[3 * l + k] = 0; }
@@ -187,11 +187,17 @@ extern "C" int ws_pyramid_build(ws_neighbors_ws* nws, ws_subsample_ws* sws, ws_p
             last_s = pts[l]; last_r = d->r_pool[l];
             d->width[3 * l + 1] = d->limit[l];
             const float r_up = d->r_up[l];
-            if ((rc = ws_radius_neighbors_search_async(nws, pts[l], n, pts[l + 1], m, d->lens[l], d->lens[l + 1], nb, r_up, d->limit[l + 1],
-                                                       nullptr, (int64_t*)(A.base + d->off_upsamples[l]), slots + 3 * l + 2, st)))
+            if (d->nearest_up) {
+                // opt-in: only the nearest support of every point (what closest_pool reads of an upsampling matrix)
+                if ((rc = ws_radius_neighbors_nearest_async(nws, pts[l], n, pts[l + 1], m, d->lens[l], d->lens[l + 1], nb, r_up, nullptr,
+                                                            (int64_t*)(A.base + d->off_upsamples[l]), slots + 3 * l + 2, st)))
+                    return rc;
+            } else if ((rc = ws_radius_neighbors_search_async(nws, pts[l], n, pts[l + 1], m, d->lens[l], d->lens[l + 1], nb, r_up,
+                                                              d->limit[l + 1], nullptr, (int64_t*)(A.base + d->off_upsamples[l]),
+                                                              slots + 3 * l + 2, st)))
                 return rc;
             last_s = pts[l + 1]; last_r = r_up;
-            d->width[3 * l + 2] = d->limit[l + 1];
+            d->width[3 * l + 2] = d->nearest_up ? 1 : d->limit[l + 1];
         }
     }
     // lengths of every level in one copy; true maximum row lengths back to the host; one synchronisation for all of it

@@ -174,7 +174,7 @@ class PyramidDesc(_C.Structure):
                  ("arena", _C.c_void_p), ("arena_bytes", _C.c_int64), ("scratch", _C.c_void_p), ("scratch_bytes", _C.c_int64),
                  ("conv_on", _C.c_int32 * _ML), ("pool_on", _C.c_int32 * _ML),
                  ("r_conv", _C.c_float * _ML), ("r_pool", _C.c_float * _ML), ("r_up", _C.c_float * _ML), ("dl", _C.c_float * _ML),
-                 ("limit", _C.c_int32 * (_ML + 1)), ("reserved1", _C.c_int32),
+                 ("limit", _C.c_int32 * (_ML + 1)), ("nearest_up", _C.c_int32),
                  ("lens", (_C.c_int32 * _MB) * _ML),
                  ("needed_bytes", _C.c_int64), ("n", _C.c_int64 * _ML)]
                 + [(name, _C.c_int64 * _ML) for name in ("off_points", "off_neighbors", "off_pools", "off_upsamples", "off_order",
@@ -214,6 +214,14 @@ def _schedule(config, limits):
     return levels
 
 
+def nearest_upsample_only(config):
+    """opt-in (config.nearest_upsample_only = True or WEASAL_NEAREST_UPSAMPLE=1; one-call pyramid only): the upsampling
+    matrices of the batch hold the nearest support of every point, [N, 1], instead of the full cropped rows.  KP-FCNN reads
+    their first column only (models/blocks.py:92-111), so the network computes the same values; the reference's batch carries
+    the full rows, which stays the default."""
+    return bool(getattr(config, "nearest_upsample_only", False)) or _os.environ.get("WEASAL_NEAREST_UPSAMPLE", "0") != "0"
+
+
 def native_eligible(config, points, lens, limits):
     return (NATIVE_PYRAMID and points.is_cuda and len(limits) > 0 and 1 <= len(lens) <= _MB
             and len(_schedule(config, limits)) <= _ML)
@@ -238,6 +246,7 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
     d = PyramidDesc()
     d.n_levels, d.nb, d.want_grids = L, B, 1 if (search_grids is not None and ops.GRID_BACKWARD) else 0
     d.want_tables = 1 if tables is not None else 0
+    d.nearest_up = 1 if nearest_upsample_only(config) else 0
     d.points, d.n0 = P0.data_ptr(), n0
     for l, lv in enumerate(levels):
         d.conv_on[l], d.pool_on[l] = int(lv["conv_on"]), int(lv["pool_on"])
