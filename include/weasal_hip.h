@@ -226,7 +226,7 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws,
                                      int32_t* d_max_count, void* stream);
 /* Nearest neighbour only (opt-in): out [nq] = column 0 of the row ws_radius_neighbors_search_async would write -- the support
  * with the smallest (distance, index) inside `radius`, or ns -- without building and sorting the row.  For the UPSAMPLING
- * searches of the pyramid, of which KP-FCNN reads the first column only (models/blocks.py:92-111); *d_any (device) becomes
+ * searches of the pyramid, of which KP-FCNN reads the first column only (models/blocks.py:80-92); *d_any (device) becomes
  * 1 if any query found a support, else 0.  Same grid reuse (ws_radius_neighbors_reuse_grid) as the full search. */
 int ws_radius_neighbors_nearest_async(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
                                       int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void nb_fill128_kernel(const float* __restrict
 }
 
 // Nearest neighbour only: column 0 of the row the full search would write (the smallest (d2, index) key inside the radius),
-// or ns.  What KP-FCNN reads of an UPSAMPLING matrix (closest_pool / nearest upsampling: models/blocks.py:92-111 take
+// or ns.  What KP-FCNN reads of an UPSAMPLING matrix (closest_pool / nearest upsampling: models/blocks.py:80-92 take
 // inds[:, 0]) -- without the compaction and the sort of a 60 .. 550-entry row.  Opt-in (ws_radius_neighbors_nearest_async).
 template <typename OutT>
 __global__ __launch_bounds__(256) void nb_nearest_kernel(const float* __restrict__ queries, int64_t nq,

@@ -217,7 +217,7 @@ def _schedule(config, limits):
 def nearest_upsample_only(config):
     """opt-in (config.nearest_upsample_only = True or WEASAL_NEAREST_UPSAMPLE=1; one-call pyramid only): the upsampling
     matrices of the batch hold the nearest support of every point, [N, 1], instead of the full cropped rows.  KP-FCNN reads
-    their first column only (models/blocks.py:92-111), so the network computes the same values; the reference's batch carries
+    their first column only (models/blocks.py:80-92), so the network computes the same values; the reference's batch carries
     the full rows, which stays the default."""
     return bool(getattr(config, "nearest_upsample_only", False)) or _os.environ.get("WEASAL_NEAREST_UPSAMPLE", "0") != "0"
 
