@@ -29,7 +29,8 @@ def _bench(*args):
                                                (("--workload", "vaihingen"), "f32", 12000),
                                                (("--workload", "vaihingen_wl"), "f32", 6000),
                                                (("--workload", "dales_deform"), "bf16", 400000),
-                                               (("--prefetch", "0", "--contrast", "0"), "f32", 400000)])
+                                               (("--prefetch", "0", "--contrast", "0"), "f32", 400000),
+                                               (("--nearest-upsample", "1"), "f32", 400000)])
 def test_bench_line_of_every_workload(args, dtype, points):
     d = _bench(*args)
     for k in KEYS:
@@ -41,3 +42,4 @@ def test_bench_line_of_every_workload(args, dtype, points):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["config"]["library_launches_per_step"] > 50
     assert "cpu_baseline" not in d                   # (--no-cpu-baseline)
+    assert ("OPT-IN nearest-only" in d["config"]["workload"]) == ("--nearest-upsample" in args)
