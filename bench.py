@@ -305,7 +305,7 @@ def main():
             while True:
                 yield inputs[i % nd]
                 i += 1
-        prefetcher = PyramidPrefetcher(cfg, endless(), wl["limits"], depth=2, device=dev)
+        prefetcher = PyramidPrefetcher(cfg, endless(), wl["limits"], depth=2, device=dev, for_training=args.mode == "train")
 
     from weasal_amd.trainer import InFlightLimiter
     limiter = InFlightLimiter(depth=4)
@@ -323,7 +323,7 @@ def main():
             served[0] += 1
         else:
             pts, feats, labels, lens = inputs[i % nd]
-            batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"])
+            batch = pyramid.build_batch(cfg, pts, feats, labels, lens, wl["limits"], for_training=args.mode == "train")
         if args.mode == "infer":
             with torch.no_grad():
                 out = net(batch, cfg)

@@ -260,7 +260,7 @@ def simple_block(block, x, batch, q_pts, s_pts, inds):
     g.in_dim = g.conv_in = conv.in_channels
     g.conv_out = g.out_dim = conv.out_channels
     g.slope = 0.1
-    if x.requires_grad and g.grid is None:
+    if torch.is_grad_enabled() and x.requires_grad and g.grid is None:
         g.table = ops.transposed_table(g.inds, g.s_pts.shape[0])
     return _KPBlockFn.apply(x, None, None, conv.weights, block.batch_norm.epilogue_bias(), None, None, None, None, g)
 
@@ -272,7 +272,7 @@ def resnetb_block(block, x, batch, q_pts, s_pts, inds):
     g = _geometry(conv, q_pts, s_pts, inds, strided)
     g.in_dim, g.conv_in, g.conv_out, g.out_dim = block.in_dim, conv.in_channels, conv.out_channels, block.out_dim
     g.slope = 0.1
-    if g.grid is None or strided:
+    if torch.is_grad_enabled() and (g.grid is None or strided):       # (only a backward reads the table)
         g.table = ops.transposed_table(g.inds, g.s_pts.shape[0])
     u1 = block.unary1 if isinstance(block.unary1, torch.nn.Module) and hasattr(block.unary1, "mlp") else None
     us = block.unary_shortcut if hasattr(block.unary_shortcut, "mlp") else None
@@ -347,5 +347,5 @@ def upunary_eligible(x, skip, unary):
 def upunary(x, skip, unary, ups):
     ups = ups.contiguous()
     ups = ups if ups.dtype == torch.int64 else ups.to(torch.int64)
-    table = ops.col0_table(ups, x.shape[0])
+    table = ops.col0_table(ups, x.shape[0]) if torch.is_grad_enabled() else None      # (only the backward reads it)
     return _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, not unary.no_relu)

@@ -823,7 +823,7 @@ class _ClosestPool(torch.autograd.Function):
         check(_by_dtype(lib, "ws_closest_pool_fwd", x)(ptr(x), ns, c, ptr(inds), nq, h, ptr(out), current_stream()))
         # only the first column takes part (blocks.py:92): the backward needs the transposed
         # table of that column alone (lists of ~N_fine/N_coarse entries instead of ~H times that)
-        ctx.table = col0_table(inds, ns)
+        ctx.table = col0_table(inds, ns) if torch.is_grad_enabled() or x.requires_grad else None
         ctx.nq = nq
         ctx.ns = ns
         return out

@@ -47,10 +47,11 @@ class PyramidPrefetcher:
     forked DataLoader workers, each with its own copy of the state: there is no single reference stream to match)."""
 
     def __init__(self, config, source, neighborhood_limits=(), depth=2, random_grid_orient=True, device=None, seed=None,
-                 workers=None):
+                 workers=None, for_training=True):
         self.config = config
         self.limits = neighborhood_limits
         self.rgo = random_grid_orient
+        self.for_training = bool(for_training)       # False: forward-only consumers (no tables / grids for a backward)
         self.source = iter(source)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         import os
@@ -122,7 +123,7 @@ class PyramidPrefetcher:
                         break
                     seq, (points, features, labels, lengths), rng = got
                     batch = pyramid.build_batch(self.config, points, features, labels, lengths, self.limits, self.rgo,
-                                                rng=rng if rng is not None else self.rngs[w])
+                                                rng=rng if rng is not None else self.rngs[w], for_training=self.for_training)
                     with self._cv:
                         self._done[seq] = batch
                         self._cv.notify_all()

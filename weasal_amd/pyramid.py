@@ -498,17 +498,23 @@ class PyramidBatch:
 
 
 def build_batch(config, points, features, labels, lengths, neighborhood_limits=(), random_grid_orient=True,
-                with_tables=True, rng=None):
+                with_tables=True, rng=None, for_training=True):
+    """for_training=False (forward-only use: the testers' pass): no transposed tables, no exported search grids / key_last --
+    nothing a backward would need"""
+    if not for_training:
+        with_tables = False
     orders, grids, radii = [], [], []
     lens_np = np.asarray(lengths.cpu() if isinstance(lengths, torch.Tensor) else lengths, dtype=np.int32)
     native = native_eligible(config, points, lens_np, neighborhood_limits)
     tables = {} if (native and with_tables) else None
     if native:
         li = segmentation_inputs_native(config, points, features, labels, lens_np, neighborhood_limits, random_grid_orient,
-                                        point_orders=orders, search_grids=grids, rng=rng, search_radii=radii, tables=tables)
+                                        point_orders=orders, search_grids=grids if for_training else None, rng=rng,
+                                        search_radii=radii, tables=tables)
     else:
         li = segmentation_inputs(config, points, features, labels, lens_np, neighborhood_limits, random_grid_orient,
-                                 point_orders=orders, search_grids=grids if points.is_cuda else None, rng=rng, search_radii=radii)
+                                 point_orders=orders, search_grids=grids if (points.is_cuda and for_training) else None, rng=rng,
+                                 search_radii=radii)
     batch = PyramidBatch(li, orders)
     batch.search_grids = grids
     batch.search_radii = radii
