@@ -132,7 +132,7 @@ def cpu_pyramid_rate(cfg_name, wl, procs):
 
 
 def cpu_baseline(cfg_cls, wl, threads):
-    """Reference CPU path on a bounded sample: ONE sphere of the workload through
+    """Reference CPU path on a bounded sample: up to FOUR spheres of the workload (half a DALES batch) through
     (a) the pyramid on the CPU geometry core, single thread like one DataLoader worker,
     (b) KPFCNN forward + loss + backward in plain torch on all host threads;
     plus (c) the pyramid rate of 10 worker processes (the reference's input_threads), one sphere each."""
@@ -144,7 +144,8 @@ def cpu_baseline(cfg_cls, wl, threads):
     cfg = cfg_cls()
     cfg.feature_dtype = 'f32'          # the CPU restatement is the reference's fp32 arithmetic
     kind = "ref" if geom.have_ref() else "port"
-    pts, feats, labels, lens = make_inputs(12345, 1, wl["points"], wl["radius"], cfg.in_features_dim)
+    n_sph = min(4, int(wl["spheres"]))      # a bounded sample: ~10 s of CPU work on the DALES workload
+    pts, feats, labels, lens = make_inputs(12345, n_sph, wl["points"], wl["radius"], cfg.in_features_dim)
     np.random.seed(0)
     t0 = time.perf_counter()
     li = pyramid_ref.segmentation_inputs(cfg, pts, feats, labels, lens, wl["limits"], kind=kind)
@@ -169,9 +170,9 @@ def cpu_baseline(cfg_cls, wl, threads):
             "pyramid_points_per_s_10_processes": pyr10, "pyramid_10_processes_wall_s": wall10,
             "model_points_per_s": n / t_model,
             "kind": "reference" if kind == "ref" else "port",
-            "sample": "1 sphere x %d pts: pyramid %.2fs on 1 thread (%s geometry core) + KPFCNN fwd+bwd %.2fs "
+            "sample": "%d sphere(s), %d pts: pyramid %.2fs on 1 thread (%s geometry core) + KPFCNN fwd+bwd %.2fs "
                       "in plain torch (oracle/kpconv_ref.py restatement of models/blocks.py) on %d threads"
-                      % (n, t_pyr, "oracle/_ref = the reference's own C++" if kind == "ref" else "oracle port", t_model, threads)}
+                      % (n_sph, n, t_pyr, "oracle/_ref = the reference's own C++" if kind == "ref" else "oracle port", t_model, threads)}
 
 
 def self_launch(n):
