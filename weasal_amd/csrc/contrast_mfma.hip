@@ -27,7 +27,7 @@ __device__ __forceinline__ void lds_order()
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
-constexpr int CF_TILES = 8;            // point tiles (of 16) per wave
+constexpr int CF_TILES = 2;            // point tiles (of 16) per wave (8: 371 us, 4: 358 us, 2: 318 us at N = 400 000: more workgroups hide more latency)
 constexpr int CF_WAVES = 8;            // waves per workgroup: they share one 56 KB slice table (two workgroups per CU = 4 waves per SIMD)
 
 template <int NS>                      // NS = ceil(C / 4) MFMA steps per tile
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(512) void contrast_fwd_mfma_kernel(const float* __r
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
-constexpr int CB_TILES = 8;            // point tiles per wave: 128 points per wave, 512 per workgroup
+constexpr int CB_TILES = 4;            // point tiles per wave: 64 points per wave, 256 per workgroup (8: 771 us, 4: 561 us + 8 us more reduction)
 constexpr int CB_WLD = 17;             // pitch of the W scratch tile
 
 template <int NS>
