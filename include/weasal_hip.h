@@ -219,6 +219,10 @@ int ws_radius_neighbors_search(ws_neighbors_ws* ws,
  * kernel); the caller checks the value later (e.g. once per batch for all its searches) and repeats
  * a search with ws_radius_neighbors_search if it was larger, or trims columns if it was smaller than
  * `width`.  An empty result shows as *d_max_count == 0. */
+/* capacity (neighbours inside the radius per query) of the row slab ws_radius_neighbors_search_async uses for rows of `width`
+ * entries: 128 up to width 128, else 576 / 704 / 1024; a maximum count beyond it (d_max_count) means truncated candidates:
+ * the caller repeats that search with the two-call protocol. */
+int32_t ws_radius_neighbors_async_cap(int32_t width);
 int ws_radius_neighbors_search_async(ws_neighbors_ws* ws,
                                      const float* queries, int64_t nq, const float* supports, int64_t ns,
                                      const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,

@@ -427,9 +427,13 @@ def test_one_call_pyramid_equals_the_per_call_loop():
                 assert (ga.nb, ga.cells, ga.ns, ga.max_count, ga.cap) == (gb.nb, gb.cells, gb.ns, gb.max_count, gb.cap)
                 assert abs(ga.radius - gb.radius) == 0.0
             for ta, tb in ((ref.tables, got.tables), (ref.col0_tables, got.col0_tables)):
-                assert len(ta) == len(tb)
-                for (ma, nsa, xa), (mb, nsb, xb) in zip(ta, tb):
-                    assert nsa == nsb and torch.equal(ma, mb)
+                # (a convolution level whose search overflowed the asynchronous slab has no grid: the per-call loop pre-builds
+                # its table, the one-call path leaves it to the first backward -- every table the latter has must match)
+                assert len(tb) <= len(ta) and len(tb) >= len(ta) - len(ref.points)
+                for mb, nsb, xb in tb:
+                    hits = [(ma, nsa, xa) for ma, nsa, xa in ta if nsa == nsb and ma.shape == mb.shape and torch.equal(ma, mb)]
+                    assert len(hits) >= 1
+                    ma, nsa, xa = hits[0]
                     assert torch.equal(xa.offsets[:nsa + 1], xb.offsets[:nsb + 1])
                     n_pairs = int(xa.offsets[nsa])
                     assert torch.equal(xa.pairs[:n_pairs], xb.pairs[:n_pairs])

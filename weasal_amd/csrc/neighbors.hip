@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void nb_nearest_kernel(const float* __restrict
 // slots INSIDE a bucket, which the final within-bucket count makes irrelevant: bit-identical rows from run to run.
 // With NB = 256 a 500-key row has ~2 keys per bucket (~8 in the fullest): the within-bucket count is a handful of LDS
 // reads per key, taken for all of a lane's keys together (independent chains).
-template <typename OutT>
+template <typename OutT, int CAP>
 __global__ __launch_bounds__(256) void nb_fill_wide_kernel(const float* __restrict__ queries, int64_t nq,
                                                            const CloudGrid* __restrict__ grids, int nb,
                                                            const int32_t* __restrict__ cell_start,
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void nb_fill_wide_kernel(const float* __restri
                                                            int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
                                                            unsigned long long* __restrict__ key_last)
 {
-    constexpr int CAP = 1024, NB = 256, KPL = CAP / 64;
+    constexpr int NB = 256, KPL = CAP / 64;       // CAP = 576 / 704 / 1024 keys per query: 8.3 / 9.5 / 12.7 KB of LDS per wave = 4 / 4 / 3 workgroups per CU
     __shared__ unsigned long long slab_all[4][CAP + 64];      // keys in arrival order (+ one dummy slot per lane)
     __shared__ unsigned short member_all[4][CAP];             // slab positions grouped by bucket
     __shared__ int hist_all[4][NB];
@@ -896,6 +896,7 @@ struct KeyLastGuard {
 };
 
 // lab switches (tools/k1_lab.py): grid cap and queries per workgroup of the fill launch
+extern "C" int ws_nb_wide_caps = 1;       // 1: slab of the wide asynchronous search sized to the width (576 / 704 / 1024), 0: always 1024 (A/B: WEASAL_NB_WIDE_CAPS)
 extern "C" int ws_nb_max_blocks = 0;
 extern "C" int ws_nb_queries_per_block = 0;
 
@@ -925,12 +926,13 @@ static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* 
 #undef WS_NB128
     }
     else if (cap <= 1024) {
-        if (out_i32)
-            nb_fill_wide_kernel<int32_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
-                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i32, cn, mx, kl);
-        else
-            nb_fill_wide_kernel<int64_t><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,
-                                                               ws->sorted.p, ws->r2, ws->ns, width, qo, out_i64, cn, mx, kl);
+#define WS_NBW(OT, CAPV, OUT)                                                                                          \
+    nb_fill_wide_kernel<OT, CAPV><<<grid, 256, 0, st>>>(ws->queries, ws->nq, ws->grids.p, ws->nb, ws->cell_start.p,    \
+                                                        ws->sorted.p, ws->r2, ws->ns, width, qo, OUT, cn, mx, kl)
+        if (cap <= 576) { if (out_i32) WS_NBW(int32_t, 576, out_i32); else WS_NBW(int64_t, 576, out_i64); }
+        else if (cap <= 704) { if (out_i32) WS_NBW(int32_t, 704, out_i32); else WS_NBW(int64_t, 704, out_i64); }
+        else { if (out_i32) WS_NBW(int32_t, 1024, out_i32); else WS_NBW(int64_t, 1024, out_i64); }
+#undef WS_NBW
     }
     else if (cap <= 2048) WS_NB_FILL(2048);
     else return ws_fail(WS_ERR_UNSUPPORTED, "max neighbour count %d exceeds the 2048-entry sort slab", cap);
@@ -967,6 +969,19 @@ int ws_radius_neighbors_search(ws_neighbors_ws* ws, const float* queries, int64_
     }
 }
 
+// Row slab of the asynchronous search for rows of `width` entries.  The slab must hold EVERY neighbour inside the radius (the row
+// keeps the nearest `width` of them); the calibrated limits are 90th percentiles of the counts, the largest count of a batch lies
+// 5-20 % above them (config 5: limits 422 / 519 / 472, maxima 491 / 552 / 565), so 5/4 of the width rounded up to the next
+// kernel variant covers it with fewer LDS bytes per wave (4 instead of 3 workgroups per CU); a batch that does overflow is
+// reported through d_max_count and redone by the caller, as before.
+int32_t ws_radius_neighbors_async_cap(int32_t width)
+{
+    if (width <= 128) return 128;
+    if (!ws_nb_wide_caps) return 1024;
+    const int need = width + width / 4;
+    return need <= 576 ? 576 : (need <= 704 ? 704 : 1024);
+}
+
 int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, int64_t nq, const float* supports,
                                      int64_t ns, const int32_t* h_q_lens, const int32_t* h_s_lens, int32_t nb,
                                      float radius, int32_t width, int32_t* out_i32, int64_t* out_i64,
@@ -981,7 +996,7 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, 
     if (rc) { if (ws) ws->nq = 0; return rc; }
     // rows wider than the 128-entry fast path are asked for (deformable radius): the 1024-key bucketed sort from the start,
     // instead of a 128-entry pass the caller would have to repeat
-    const int cap = width > 128 ? 1024 : 128;
+    const int cap = ws_radius_neighbors_async_cap(width);
     if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st))) return rc;   // max-count word cleared by nb_prepare
     WS_HIP(hipMemcpyAsync(d_max_count, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     ws->max_count_host = cap;   // unknown on the host; rows beyond the slab are reported through d_max_count

@@ -215,7 +215,7 @@ extern "C" int ws_pyramid_build(ws_neighbors_ws* nws, ws_subsample_ws* sws, ws_p
         for (int k = 0; k < 3; ++k) {
             const int w = d->width[3 * l + k], mc = d->max_count[3 * l + k];
             if (w <= 0) continue;
-            const int cap = w > 128 ? 1024 : 128;
+            const int cap = ws_radius_neighbors_async_cap(w);
             if (mc <= 0 || mc > cap) continue;                       // empty result / slab overflow: the caller's business
             d->final_width[3 * l + k] = w;
             if (mc < w) {

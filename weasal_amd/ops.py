@@ -970,6 +970,15 @@ def radius_neighbors(queries, supports, q_lens, s_lens, radius, limit=None, dtyp
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def widen_async_slabs(max_count):
+    """a row overflowed the width-sized slab of the asynchronous search (ws_radius_neighbors_async_cap: 5/4 of the limit): this
+    data has longer tails than that -- from now on the process uses the full 1024-entry slab for wide rows, so that the
+    repeat of a search (synchronous, two passes) stays a one-off instead of a per-batch cost"""
+    import ctypes as C
+    if max_count <= 1024:
+        C.c_int.in_dll(_lib.lib(), "ws_nb_wide_caps").value = 0
+
+
 class DeferredSearches:
     """Batch of radius searches issued without host synchronisation (ws_radius_neighbors_search_async).
     ``add`` returns the index matrix immediately ([Nq, limit], rows padded with Ns); ``finish`` reads
@@ -1005,7 +1014,7 @@ class DeferredSearches:
             if want_grid:
                 grid = SearchGrid()
                 grid.max_count = 0            # true maximum row length of the search: set by the caller after finish()
-                grid.cap = 1024 if width > 128 else 128      # sort slab of the asynchronous pass: key_last is valid up to it
+                grid.cap = int(lib.ws_radius_neighbors_async_cap(width))      # sort slab of the asynchronous pass: key_last is valid up to it
                 grid.key_last = torch.empty((q.shape[0],), dtype=torch.int64, device=q.device)
                 grid.radius = float(np.float32(radius))
                 grid.overflow = torch.zeros((1,), dtype=torch.int32, device=q.device)
@@ -1037,7 +1046,8 @@ class DeferredSearches:
             q, s, ql, sl, radius, width = args
             if mc == 0:
                 raise _lib.WeasalHipError("libweasal_hip status 4: Error")
-            if mc > (1024 if width > 128 else 128):      # beyond the sort slab the asynchronous pass used
+            if mc > int(_lib.lib().ws_radius_neighbors_async_cap(int(width))):      # beyond the sort slab the asynchronous pass used
+                widen_async_slabs(mc)
                 out = radius_neighbors(q, s, ql, sl, radius, limit=width, dtype=torch.int64)
             elif mc < width:
                 out = out[:, :int(mc)].contiguous()

@@ -310,7 +310,7 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
     lens_host = [np.array(d.lens[l][:B], dtype=np.int32) for l in range(L)]
     slots = view(d.off_slots, 4 * L * 4, torch.int32, (4 * L,))
     empty_i = lambda: torch.zeros((0, 1), dtype=torch.int64, device=dev)
-    cap_of = lambda width: 1024 if width > 128 else 128
+    cap_of = lambda width: int(lib.ws_radius_neighbors_async_cap(int(width)))
 
     def finish(l, kind, off, rows, q, s, ql, sl, radius):
         """the matrix of search (l, kind) as the reference's crop leaves it: trimmed to the true width when that is smaller
@@ -321,6 +321,7 @@ def segmentation_inputs_native(config, stacked_points, stacked_features, labels,
         if fw > 0:                                     # cropped in place to the widest row where that is below the limit
             mat = view(off, rows * fw * 8, torch.int64, (rows, fw))
         else:                                          # a row beyond the asynchronous search's slab
+            ops.widen_async_slabs(mc)
             mat = ops.radius_neighbors(q, s, ql, sl, radius, limit=width, dtype=torch.int64)
         if search_radii is not None:
             search_radii.append((mat, float(radius)))
