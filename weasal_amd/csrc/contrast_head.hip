@@ -257,35 +257,31 @@ __global__ __launch_bounds__(256) void contrast_tail_bwd_kernel(const float* __r
 }
 
 // slice-row gradients back onto their points: the FIRST slot of a point adds all its slots in slot order (deterministic).
-// 16 lanes per slot: they scan the slot table together (is there an earlier slot of the same point?  later ones?); later
-// duplicates are rare (about one per 1000 draws out of 400 000) and then added one after the other.
+// One wave per slot: its 64 lanes compare the slot's point with 64 table entries at a time (two ballots per round: an earlier
+// slot of the same point?  a later one?); later duplicates are rare (about one per 1000 draws out of 400 000) and then added
+// one after the other by the lanes that own a channel.
 __global__ __launch_bounds__(256) void contrast_slice_add_kernel(const float* __restrict__ d_xs, const int64_t* __restrict__ slc_idx,
                                                                   int s, int c, float* __restrict__ d_on)
 {
     __shared__ int idx[2048];
     for (int j = threadIdx.x; j < s; j += 256) idx[j] = (int)slc_idx[j];
     __syncthreads();
-    const int j = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
-    const bool live = j < s;
-    const int me = live ? idx[j] : -1;
-    int before = 0, after = 0;
-    if (live)
-        for (int q = l; q < s; q += 16) {
-            const bool same = idx[q] == me;
-            before += (same && q < j) ? 1 : 0;
-            after += (same && q > j) ? 1 : 0;
-        }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        before += __shfl_xor(before, o, 16);
-        after += __shfl_xor(after, o, 16);
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= s) return;                                              // (wave-uniform)
+    const int me = idx[j];
+    bool earlier = false, later = false;
+    for (int q0 = 0; q0 < s; q0 += 64) {
+        const int q = q0 + lane;
+        const bool same = q < s && idx[q] == me;
+        earlier = earlier || __ballot(same && q < j) != 0ull;
+        later = later || __ballot(same && q > j) != 0ull;
     }
-    if (!live || before > 0 || l >= c) return;
-    float a = d_on[(int64_t)me * c + l] + d_xs[(int64_t)j * c + l];
-    if (after > 0)
+    if (earlier || lane >= c) return;
+    float a = d_on[(int64_t)me * c + lane] + d_xs[(int64_t)j * c + lane];
+    if (later)
         for (int q = j + 1; q < s; ++q)
-            if (idx[q] == me) a += d_xs[(int64_t)q * c + l];
-    d_on[(int64_t)me * c + l] = a;
+            if (idx[q] == me) a += d_xs[(int64_t)q * c + lane];
+    d_on[(int64_t)me * c + lane] = a;
 }
 
 __global__ __launch_bounds__(256) void contrast_normalize_bwd_kernel(const float* __restrict__ d_on, const float* __restrict__ on,
@@ -380,7 +376,7 @@ int ws_contrast_head_bwd(float* d_on, const float* d_xs, const int64_t* slc_idx,
     WS_REQUIRE(d_on && d_xs && slc_idx && on && inv_norm && d_x, "NULL argument");
     WS_REQUIRE(n >= 1 && c >= 1 && c <= CH_CMAX && s >= 1 && s <= 2048 && ldd >= c, "size out of range");
     hipStream_t st = (hipStream_t)stream;
-    contrast_slice_add_kernel<<<(unsigned)ws_ceil_div(s, 16), 256, 0, st>>>(d_xs, slc_idx, s, c, d_on);
+    contrast_slice_add_kernel<<<(unsigned)ws_ceil_div(s, 4), 256, 0, st>>>(d_xs, slc_idx, s, c, d_on);
     WS_LAUNCH_CHECK();
     contrast_normalize_bwd_kernel<<<(unsigned)ws_ceil_div(n, 256), 256, 0, st>>>(d_on, on, inv_norm, n, c, d_x, ldd);
     WS_LAUNCH_CHECK();
