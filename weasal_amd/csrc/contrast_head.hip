@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void contrast_tail_bwd_kernel(const float* __r
 // slice-row gradients back onto their points: the FIRST slot of a point adds all its slots in slot order (deterministic).
 // One wave per slot: its 64 lanes compare the slot's point with 64 table entries at a time (two ballots per round: an earlier
 // slot of the same point?  a later one?); later duplicates are rare (about one per 1000 draws out of 400 000) and then added
-// one after the other by the lanes that own a channel.
+// in slot order by the lanes that own a channel.
 __global__ __launch_bounds__(256) void contrast_slice_add_kernel(const float* __restrict__ d_xs, const int64_t* __restrict__ slc_idx,
                                                                   int s, int c, float* __restrict__ d_on)
 {
@@ -276,12 +276,20 @@ __global__ __launch_bounds__(256) void contrast_slice_add_kernel(const float* __
         earlier = earlier || __ballot(same && q < j) != 0ull;
         later = later || __ballot(same && q > j) != 0ull;
     }
-    if (earlier || lane >= c) return;
-    float a = d_on[(int64_t)me * c + lane] + d_xs[(int64_t)j * c + lane];
-    if (later)
-        for (int q = j + 1; q < s; ++q)
-            if (idx[q] == me) a += d_xs[(int64_t)q * c + lane];
-    d_on[(int64_t)me * c + lane] = a;
+    if (earlier) return;                                             // (wave-uniform: all 64 lanes stay for the ballots below)
+    const int ch = lane < c ? lane : 0;
+    float a = d_on[(int64_t)me * c + ch] + d_xs[(int64_t)j * c + ch];
+    if (later)          // rare; 64 table entries per round again (a slot-by-slot loop here kept ONE wave busy for ~50 us)
+        for (int q0 = (j + 1) & ~63; q0 < s; q0 += 64) {
+            const int q = q0 + lane;
+            unsigned long long m = __ballot(q < s && q > j && idx[q] == me);
+            while (m) {                                              // ascending slots
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                a += d_xs[(int64_t)(q0 + b) * c + ch];
+            }
+        }
+    if (lane < c) d_on[(int64_t)me * c + lane] = a;
 }
 
 __global__ __launch_bounds__(256) void contrast_normalize_bwd_kernel(const float* __restrict__ d_on, const float* __restrict__ on,
