@@ -897,7 +897,10 @@ struct KeyLastGuard {
 
 // lab switches (tools/k1_lab.py): grid cap and queries per workgroup of the fill launch
 extern "C" int ws_nb_wide_caps = 1;       // 1: slab of the wide asynchronous search sized to the width (576 / 704 / 1024), 0: always 1024 (A/B: WEASAL_NB_WIDE_CAPS)
-extern "C" int ws_nb_max_blocks = 0;
+// grid cap of the fill launch.  1 024 workgroups (4 per CU: the fill's queries are walked in cell order either way) instead of
+// 4 096: the search alone is as fast (tools/k1_lab2.py: +-3 %), and the training stream it shares the GPU with gets wave slots
+// back -- DALES step 13.53 -> 13.42 ms, inference 5.20 -> 5.09 ms, config 5 38.7 -> 38.4 ms (A/B: WEASAL_NB_MAX_BLOCKS, 0 = 4 096)
+extern "C" int ws_nb_max_blocks = 1024;
 extern "C" int ws_nb_queries_per_block = 0;
 
 static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* out_i32, int64_t* out_i64,
