@@ -898,8 +898,8 @@ struct KeyLastGuard {
 // lab switches (tools/k1_lab.py): grid cap and queries per workgroup of the fill launch
 extern "C" int ws_nb_wide_caps = 1;       // 1: slab of the wide asynchronous search sized to the width (576 / 704 / 1024), 0: always 1024 (A/B: WEASAL_NB_WIDE_CAPS)
 // grid cap of the fill launch.  1 024 workgroups (4 per CU: the fill's queries are walked in cell order either way) instead of
-// 4 096: the search alone is as fast (tools/k1_lab2.py: +-3 %), and the training stream it shares the GPU with gets wave slots
-// back -- DALES step 13.53 -> 13.42 ms, inference 5.20 -> 5.09 ms, config 5 38.7 -> 38.4 ms (A/B: WEASAL_NB_MAX_BLOCKS, 0 = 4 096)
+// 4 096: alone the 13 searches of a pyramid take 1.29 instead of 1.08 ms (tools/k1_lab2.py), but they run under the training
+// stream, which gets wave slots back -- DALES step 13.53 -> 13.42 ms, inference 5.20 -> 5.09 ms, config 5 38.7 -> 38.4 ms (A/B: WEASAL_NB_MAX_BLOCKS, 0 = 4 096)
 extern "C" int ws_nb_max_blocks = 1024;
 extern "C" int ws_nb_queries_per_block = 0;
 
