@@ -555,6 +555,10 @@ typedef struct ws_upunary {
     const float* w; int64_t ldw; const float* b; int32_t out_dim; int32_t relu; float slope;
     float* yc; float* out;               /* fwd outputs (yc is scratch-like but caller-owned: not needed by bwd) */
     const float* dout; float* dxc; float* dskip; float* dw; float* db;
+    /* nn.Dropout on `out` (models/architectures.py:345-346: the droplayer in front of the head), fused: drop_p > 0 makes the
+     * forward's last epilogue write dropout(out) (keep decision = function of (drop_seed, element index), the bits of
+     * ws_dropout_apply) and the backward treat `dout` as the gradient of that dropped tensor.  Needs relu != 0. */
+    float drop_p; uint64_t drop_seed;
 } ws_upunary;
 
 int64_t ws_upunary_fwd_scratch_bytes(const ws_upunary* d);
@@ -569,6 +573,19 @@ int ws_gemm_xb_epilogue_strided(const float* x, int64_t m, int32_t k, int64_t ld
                                 int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
                                 int32_t act, float slope, float* y, int64_t ldy, void* scratch, int64_t scratch_bytes,
                                 void* stream);
+
+/* The same product with nn.Dropout applied to the activated output in the epilogue: y = keep ? act(..) / (1 - p) : 0, the keep
+ * decision of element (row, col) being that of ws_dropout_apply for index row * n + col and the same seed (bit-identical to
+ * the product followed by ws_dropout_apply on a contiguous [m, n] tensor; no mask is stored). */
+int ws_gemm_xb_dropout_strided(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride,
+                               int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
+                               int32_t act, float slope, float drop_p, uint64_t drop_seed, float* y, int64_t ldy, void* scratch,
+                               int64_t scratch_bytes, void* stream);
+
+/* ws_act_bwd_colsum for a tensor that went through that dropout: dy is the gradient of dropout(y') where y' is the activated
+ * output and y = dropout(y') is what was kept (same sign wherever the mask keeps): dz = dropout_bwd(dy) * act'(y), column sums. */
+int ws_act_bwd_colsum_dropout(const float* dy, int64_t m, int32_t n, int64_t lddy, const float* y, int64_t ldy, float slope,
+                              float drop_p, uint64_t drop_seed, float* dz, int64_t lddz, float* colsum, void* scratch, void* stream);
 
 /* The same product with multiplicative gates on the epilogue (after bias / residual / activation):
  *   gate_y [m, n] (pitch ldg, NULL = none): y *= LeakyReLU'(gate_y) = (gate_y > 0 ? 1 : gate_slope) -- when this product is the

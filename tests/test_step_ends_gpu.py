@@ -209,3 +209,79 @@ def test_training_steps_are_bit_reproducible():
         assert all(torch.equal(x, y) for x, y in zip(ma, mb))
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n", [(40003, 64, 128), (300, 2048, 256), (5001, 32, 36), (777, 9, 128)])
+def test_dropout_in_the_product_epilogue_is_the_dropout_kernel(gpu, m, k, n):
+    """ws_gemm_xb_dropout_strided (dropout of the activated output recomputed from (seed, row * n + col) in the epilogue) against
+    the product followed by ws_dropout_apply: same bits -- on the rows-on-lanes kernel, its split-K form (300 x 2048) and the
+    LDS-staged kernel (k = 9); and ws_act_bwd_colsum_dropout against dropout backward + ws_act_bwd_colsum (dz and the sums)"""
+    from weasal_amd import _lib
+    from weasal_amd._lib import check, current_stream, ptr
+    lib = _lib.lib()
+    torch.manual_seed(m + n)
+    x = torch.randn(m, k, device=gpu)
+    b = torch.randn(k, n, device=gpu)
+    bias = torch.randn(n, device=gpu)
+    res = torch.randn(m, n, device=gpu)
+    p, seed = 0.5, 987654321012345
+    scratch = torch.empty(max(int(lib.ws_gemm_xb_scratch_bytes(m, k, n)), 256), dtype=torch.uint8, device=gpu)
+    plain = torch.full((m, n), float("nan"), device=gpu)
+    fused = torch.full((m, n), float("nan"), device=gpu)
+    check(lib.ws_gemm_xb_epilogue_strided(ptr(x), m, k, k, ptr(b), n, 1, n, ptr(bias), ptr(res), n, 1, 0.1, ptr(plain), n, ptr(scratch),
+                                          scratch.numel(), current_stream()))
+    want = torch.empty_like(plain)
+    check(lib.ws_dropout_apply(ptr(plain), plain.numel(), p, seed, ptr(want), current_stream()))
+    check(lib.ws_gemm_xb_dropout_strided(ptr(x), m, k, k, ptr(b), n, 1, n, ptr(bias), ptr(res), n, 1, 0.1, p, seed, ptr(fused), n,
+                                         ptr(scratch), scratch.numel(), current_stream()))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(fused).all())
+    assert torch.equal(fused, want)
+    assert 0.45 < float((fused == 0).float().mean()) < 0.55
+    # backward: dy = gradient of the dropped tensor `want`
+    dy = torch.randn(m, n, device=gpu)
+    ddrop = torch.empty_like(dy)
+    check(lib.ws_dropout_apply(ptr(dy), dy.numel(), p, seed, ptr(ddrop), current_stream()))
+    cs = torch.empty(max(int(lib.ws_act_bwd_colsum_scratch_bytes(m, n)), 256), dtype=torch.uint8, device=gpu)
+    dz0, dz1 = torch.empty_like(dy), torch.empty_like(dy)
+    s0, s1 = torch.empty(n, device=gpu), torch.empty(n, device=gpu)
+    check(lib.ws_act_bwd_colsum(ptr(ddrop), m, n, n, ptr(plain), n, 0.1, ptr(dz0), n, ptr(s0), ptr(cs), current_stream()))
+    check(lib.ws_act_bwd_colsum_dropout(ptr(dy), m, n, n, ptr(want), n, 0.1, p, seed, ptr(dz1), n, ptr(s1), ptr(cs), current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dz0, dz1) and torch.equal(s0, s1)
+
+
+@pytest.mark.gpu
+def test_fused_dropout_step_is_the_unfused_step(monkeypatch):
+    """one Vaihingen training step with the droplayer fused into the last decoder step (forward epilogue + backward's first
+    pass) and with the dropout kernel as a pass of its own: the same seed draw, identical logits, loss and every gradient"""
+    from weasal_amd import architectures, config as wcfg, pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    dev = torch.device("cuda:0")
+    cfg = wcfg.Vaihingen3DPLConfig()
+    wl = synthetic.WORKLOADS["vaihingen"]
+    pts, feats, labels, lens = synthetic.make_inputs(7, 2, wl["points"], wl["radius"], cfg.in_features_dim)
+
+    def run(fused_on):
+        monkeypatch.setattr(architectures, "DROPOUT_FUSED", fused_on)
+        np.random.seed(1)
+        torch.manual_seed(1)
+        net = KPFCNN(cfg, np.arange(9), []).to(dev).train()
+        np.random.seed(2)
+        batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev),
+                                    torch.from_numpy(labels).to(dev), lens, wl["limits"])
+        torch.manual_seed(5)
+        out = net(batch, cfg)
+        loss = net.loss(out, batch.labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), float(loss.detach()), {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}
+
+    oa, la, ga = run(True)
+    ob, lb, gb = run(False)
+    assert float((oa == 0).float().mean()) < 0.9
+    assert torch.equal(oa, ob) and la == lb
+    assert ga.keys() == gb.keys() and len(ga) > 20
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k

@@ -21,6 +21,7 @@ from .blocks import KPConv, NearestUpsampleBlock, UnaryBlock, block_decider, clo
 _LAYER_CHANGE = ('pool', 'strided', 'upsample', 'global')
 REGULARIZER_KERNEL = os.environ.get("WEASAL_REG_KERNEL", "1") != "0"      # A/B switch: 0 = the torch-op form below
 DROPOUT_KERNEL = os.environ.get("WEASAL_DROPOUT_KERNEL", "1") != "0"       # A/B switch: 0 = nn.Dropout (the framework's kernels)
+DROPOUT_FUSED = os.environ.get("WEASAL_DROPOUT_FUSED", "1") != "0"         # A/B switch: 0 = the dropout kernel as a pass of its own
 CONTRAST_KERNELS = os.environ.get("WEASAL_CONTRAST_KERNELS", "1") != "0"  # A/B switch: 0 = contrast_loss's head / tail as torch ops
 
 
@@ -135,9 +136,10 @@ class KPFCNN(nn.Module):
         if self.feature_dtype == torch.bfloat16:
             self.head_softmax.out_f32 = True
 
-    def _fused_upsample_unary(self, x, skip, up_block, unary, batch):
+    def _fused_upsample_unary(self, x, skip, up_block, unary, batch, drop=None):
         if fused.upunary_eligible(x, skip, unary):
-            return fused.upunary(x, skip, unary, batch.upsamples[up_block.layer_ind - 1])   # one C call each way
+            return fused.upunary(x, skip, unary, batch.upsamples[up_block.layer_ind - 1], drop)   # one C call each way
+        assert drop is None
         c_up = x.shape[1]
         w = unary.mlp.weight
         y = closest_pool(ops.linear(x, w[:, :c_up]), batch.upsamples[up_block.layer_ind - 1])
@@ -159,19 +161,27 @@ class KPFCNN(nn.Module):
                 x = x.to(torch.bfloat16)     # the 3-channel input layer ran in f32; bf16 rows from here on
         nd = len(self.decoder_blocks)
         block_i = 0
+        dropped = False
         while block_i < nd:
             block_op = self.decoder_blocks[block_i]
             nxt = self.decoder_blocks[block_i + 1] if block_i + 1 < nd else None
             if (self.fuse_decoder and isinstance(block_op, NearestUpsampleBlock) and isinstance(nxt, UnaryBlock)
                     and (block_i + 1) in self.decoder_concats and block_i not in self.decoder_concats):
-                x = self._fused_upsample_unary(x, skips.pop(), block_op, nxt, batch)
+                drop = None
+                if (block_i + 2 == nd and self.dropout and DROPOUT_KERNEL and DROPOUT_FUSED and self.training and not nxt.no_relu
+                        and torch.is_grad_enabled() and x.dtype == torch.float32 and fused.upunary_eligible(x, skips[-1], nxt)):
+                    # the droplayer in front of the head (architectures.py:345-346) rides on the last decoder step's epilogue:
+                    # the same keep decisions as ops.dropout (same seed draw), no pass of its own in either direction
+                    drop = (float(self.dropout), int(torch.randint(0, 1 << 62, (1,)).item()))
+                    dropped = True
+                x = self._fused_upsample_unary(x, skips.pop(), block_op, nxt, batch, drop)
                 block_i += 2
                 continue
             if block_i in self.decoder_concats:
                 x = torch.cat([x, skips.pop()], dim=1)
             x = block_op(x, batch)
             block_i += 1
-        if self.dropout:
+        if self.dropout and not dropped:
             if DROPOUT_KERNEL and self.training and x.is_cuda and x.dtype == torch.float32 and x.requires_grad:
                 x = ops.dropout(x, float(self.dropout))          # one pass each way, mask recomputed instead of stored
             else:

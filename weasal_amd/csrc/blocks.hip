@@ -362,6 +362,8 @@ int check_upunary(const ws_upunary* d)
     if (d->c_up % 32 || d->c_skip % 32 || d->out_dim % 32 || d->ldw % 4 || ((uintptr_t)d->w & 15u))
         return ws_fail(WS_ERR_UNSUPPORTED, "decoder step: widths must be multiples of 32 (c_up=%d c_skip=%d out=%d)", d->c_up, d->c_skip,
                        d->out_dim);
+    WS_REQUIRE(d->drop_p >= 0.0f && d->drop_p < 1.0f, "bad drop probability %g", (double)d->drop_p);
+    if (d->drop_p > 0.0f && !d->relu) return ws_fail(WS_ERR_UNSUPPORTED, "decoder step: the fused dropout follows a LeakyReLU (relu = 0)");
     return WS_OK;
 }
 
@@ -376,6 +378,9 @@ int upunary_fwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
         WS_TRY(ws_gemm_xb_epilogue_strided(d->xc, d->nc, d->c_up, d->c_up, d->w, 1, d->ldw, d->out_dim, nullptr, nullptr, 0, 0, 0.0f, d->yc,
                                            d->out_dim, tmp, tmp_bytes, st));
     WS_TRY(ws_closest_pool_fwd(d->yc, d->nc, d->out_dim, d->ups, d->nf, d->h_up, up, st));
+    if (d->drop_p > 0.0f)       // the droplayer in front of the head rides on this epilogue
+        return ws_gemm_xb_dropout_strided(d->skip, d->nf, d->c_skip, d->c_skip, d->w + d->c_up, 1, d->ldw, d->out_dim, d->b, up, d->out_dim,
+                                          1, d->slope, d->drop_p, d->drop_seed, d->out, d->out_dim, tmp, tmp_bytes, st);
     return ws_gemm_xb_epilogue_strided(d->skip, d->nf, d->c_skip, d->c_skip, d->w + d->c_up, 1, d->ldw, d->out_dim, d->b, up, d->out_dim,
                                        d->relu ? 1 : 0, d->slope, d->out, d->out_dim, tmp, tmp_bytes, st);
 }
@@ -401,7 +406,11 @@ int upunary_bwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
     }
     // dz = dout * lrelu'(out) (identity when !relu), db
     const float* g = d->dout;
-    if (d->relu) {
+    if (d->drop_p > 0.0f) {
+        WS_TRY(ws_act_bwd_colsum_dropout(d->dout, d->nf, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, d->drop_p, d->drop_seed, dz,
+                                         d->out_dim, d->db, tmp, st));
+        g = dz;
+    } else if (d->relu) {
         WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, dz, d->out_dim, d->db, tmp, st));
         g = dz;
     } else if (d->db) {

@@ -30,9 +30,12 @@ constexpr int BK = 32;    // k depth per LDS tile
 //        activation backward of the layer that consumes this product as its gradient (dX = dY W^T gated by that layer's y);
 //   mask rows [m, n] of bytes (pitch ldm): v = mask ? v * mscale : 0 -- dropout, forward (on the activated output) and
 //        backward (on the gradient) alike.
+//   drop (drop.on): nn.Dropout with the keep decision recomputed from (seed, row * dn + col) -- dn = the row length of the
+//        contiguous tensor the reference's droplayer sees -- instead of read from a mask: v = keep ? v * scale : 0.
 struct XbGate {
     const float* y; int64_t ld; float slope;
     const uint8_t* mask; int64_t ldm; float mscale;
+    WsDrop drop; int64_t dn;
 };
 __device__ __forceinline__ void xb_gate4(float4& v, const XbGate& g, int64_t row, int col)
 {
@@ -46,11 +49,17 @@ __device__ __forceinline__ void xb_gate4(float4& v, const XbGate& g, int64_t row
         v.x = (mk & 0xffu) ? v.x * g.mscale : 0.0f;       v.y = (mk & 0xff00u) ? v.y * g.mscale : 0.0f;
         v.z = (mk & 0xff0000u) ? v.z * g.mscale : 0.0f;   v.w = (mk & 0xff000000u) ? v.w * g.mscale : 0.0f;
     }
+    if (g.drop.on) {
+        const unsigned long long i = (unsigned long long)(row * g.dn + col);
+        v.x = ws_drop1(v.x, g.drop, i); v.y = ws_drop1(v.y, g.drop, i + 1);
+        v.z = ws_drop1(v.z, g.drop, i + 2); v.w = ws_drop1(v.w, g.drop, i + 3);
+    }
 }
 __device__ __forceinline__ float xb_gate1(float v, const XbGate& g, int64_t row, int col)
 {
     if (g.y) v *= g.y[row * g.ld + col] > 0.0f ? 1.0f : g.slope;
     if (g.mask) v = g.mask[row * g.ldm + col] ? v * g.mscale : 0.0f;
+    if (g.drop.on) v = ws_drop1(v, g.drop, (unsigned long long)(row * g.dn + col));
     return v;
 }
 
@@ -211,7 +220,7 @@ __device__ __forceinline__ void xb_rows_epilogue(const f32x16 (&acc)[NT], int64_
                 v[g].w = v[g].w > 0.0f ? v[g].w : v[g].w * slope;
             }
         }
-        if (gate.y || gate.mask) {
+        if (gate.y || gate.mask || gate.drop.on) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) xb_gate4(v[g], gate, rr, col[g] < n ? col[g] : n - 4);
         }
@@ -272,7 +281,7 @@ __device__ __forceinline__ void xb_rows_epilogue_staged(const f32x16 (&acc)[NT],
                 v[p].z = v[p].z > 0.0f ? v[p].z : v[p].z * slope;
                 v[p].w = v[p].w > 0.0f ? v[p].w : v[p].w * slope;
             }
-            if (gate.y || gate.mask) xb_gate4(v[p], gate, rr[p], colc);
+            if (gate.y || gate.mask || gate.drop.on) xb_gate4(v[p], gate, rr[p], colc);
             if (live[p]) *reinterpret_cast<float4*>(y + rr[p] * ldy + col) = v[p];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -426,14 +435,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
         float* stage = &Ws[wave * XB_STAGE_FLOATS];
         if (partial)
             xb_rows_epilogue_staged<NT>(acc, row0, m, n0 + wn * (32 * NT), n, lane, partial + (int64_t)blockIdx.z * m * n, n, nullptr,
-                                        nullptr, 0, 0, 0.0f, XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f}, stage);
+                                        nullptr, 0, 0, 0.0f, XbGate{}, stage);
         else
             xb_rows_epilogue_staged<NT>(acc, row0, m, n0 + wn * (32 * NT), n, lane, y, ldy, bias, residual, ldr, act, slope, gate, stage);
         return;
     }
     if (partial)
         xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, partial + (int64_t)blockIdx.z * m * n, n, nullptr, nullptr, 0,
-                             0, 0.0f, XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f});
+                             0, 0.0f, XbGate{});
     else
         xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope, gate);
 }
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(256) void gemm_xb3_kernel(
     const int64_t row = brow0 + wave * 32 + j;
     if (partial)
         xb_rows_epilogue<NT>(acc, row, m, n0, n, h, partial + (int64_t)blockIdx.z * m * n, n, nullptr, nullptr, 0, 0, 0.0f,
-                             XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f});
+                             XbGate{});
     else
         xb_rows_epilogue<NT>(acc, row, m, n0, n, h, y, ldy, bias, residual, ldr, act, slope, gate);
 }
@@ -1038,8 +1047,10 @@ template <int V>
 __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                               int64_t m, int n, int64_t lddy, int64_t ldy, float slope,
                                                               float* __restrict__ dz, int64_t lddz,
-                                                              float* __restrict__ partial, int64_t chunk)
+                                                              float* __restrict__ partial, int64_t chunk, const WsDrop drop)
 {
+    // drop.on: dy is the gradient of a DROPPED tensor (nn.Dropout applied to the activated output y, fused into the producing
+    // epilogue): g = keep(row * n + col) ? g * scale : 0 first, exactly the separate dropout backward, then the activation
     __shared__ float red[256 * V];
     const int t = threadIdx.x;
     const int ncg = (n + V - 1) / V;                    // column groups
@@ -1060,7 +1071,12 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __rest
             const float* pg = dy + (mbeg + rl) * lddy + col;
             const float* pa = yact ? yact + (mbeg + rl) * ldy + col : nullptr;
             float* pz = yact ? dz + (mbeg + rl) * lddz + col : nullptr;
-            auto one = [&](vec_t g, vec_t a, float* out) {
+            auto one = [&](vec_t g, vec_t a, float* out, int64_t row) {
+                if (drop.on) {
+                    const unsigned long long i0 = (unsigned long long)(row * n + col);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g[e] = ws_drop1(g[e], drop, i0 + e);
+                }
                 if (pa) {
 #pragma unroll
                     for (int e = 0; e < V; ++e) g[e] = a[e] > 0.0f ? g[e] : g[e] * slope;
@@ -1078,14 +1094,14 @@ __global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __rest
                     a0 = *reinterpret_cast<const vec_t*>(pa); a1 = *reinterpret_cast<const vec_t*>(pa + sy);
                     a2 = *reinterpret_cast<const vec_t*>(pa + 2 * sy); a3 = *reinterpret_cast<const vec_t*>(pa + 3 * sy);
                 }
-                one(g0, a0, pz); one(g1, a1, pz + sdz); one(g2, a2, pz + 2 * sdz); one(g3, a3, pz + 3 * sdz);
+                one(g0, a0, pz, r); one(g1, a1, pz + sdz, r + R); one(g2, a2, pz + 2 * sdz, r + 2 * R); one(g3, a3, pz + 3 * sdz, r + 3 * R);
                 pg += 4 * sdy;
                 if (pa) { pa += 4 * sy; pz += 4 * sdz; }
             }
             for (; r < mend; r += R) {
                 vec_t g0 = *reinterpret_cast<const vec_t*>(pg);
                 vec_t a0 = pa ? *reinterpret_cast<const vec_t*>(pa) : g0;
-                one(g0, a0, pz);
+                one(g0, a0, pz, r);
                 pg += sdy;
                 if (pa) { pa += sy; pz += sdz; }
             }
@@ -1183,7 +1199,7 @@ static int gemm_xb_core(const float* x, int64_t m, int32_t k, int64_t ldx, const
 static int gemm_xb_impl(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n,
                         const float* bias, const float* residual, int64_t ldr, int32_t act, float slope,
                         float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream,
-                        int64_t brs = -1, int64_t bcs = 1, XbGate gate = XbGate{nullptr, 0, 0.0f, nullptr, 0, 0.0f})
+                        int64_t brs = -1, int64_t bcs = 1, XbGate gate = XbGate{})
 {
     if (!ws_gemm_log)
         return gemm_xb_core(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream, brs, bcs, gate);
@@ -1318,8 +1334,25 @@ int64_t ws_act_bwd_colsum_scratch_bytes(int64_t m, int32_t n)
     return ws_ceil_div(m > 0 ? m : 1, colsum_chunk(m)) * (int64_t)n * (int64_t)sizeof(float);
 }
 
+static int act_bwd_colsum_impl(const float* dy, int64_t m, int32_t n, int64_t lddy, const float* y, int64_t ldy, float slope,
+                               float* dz, int64_t lddz, float* colsum, void* scratch, void* stream, WsDrop drop);
+
 int ws_act_bwd_colsum(const float* dy, int64_t m, int32_t n, int64_t lddy, const float* y, int64_t ldy, float slope,
                       float* dz, int64_t lddz, float* colsum, void* scratch, void* stream)
+{
+    return act_bwd_colsum_impl(dy, m, n, lddy, y, ldy, slope, dz, lddz, colsum, scratch, stream, WsDrop{});
+}
+
+int ws_act_bwd_colsum_dropout(const float* dy, int64_t m, int32_t n, int64_t lddy, const float* y, int64_t ldy, float slope,
+                              float drop_p, uint64_t drop_seed, float* dz, int64_t lddz, float* colsum, void* scratch, void* stream)
+{
+    WS_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "bad drop probability %g", (double)drop_p);
+    WS_REQUIRE(y && dz, "the dropout form writes dz (it needs y and dz)");
+    return act_bwd_colsum_impl(dy, m, n, lddy, y, ldy, slope, dz, lddz, colsum, scratch, stream, ws_drop_args(drop_p, drop_seed));
+}
+
+static int act_bwd_colsum_impl(const float* dy, int64_t m, int32_t n, int64_t lddy, const float* y, int64_t ldy, float slope,
+                               float* dz, int64_t lddz, float* colsum, void* scratch, void* stream, WsDrop drop)
 {
     WS_REQUIRE(m >= 0 && n >= 1 && lddy >= n, "bad sizes m=%lld n=%d", (long long)m, n);
     WS_REQUIRE(!y || (dz && ldy >= n && lddz >= n), "activation backward needs y and dz");
@@ -1336,10 +1369,10 @@ int ws_act_bwd_colsum(const float* dy, int64_t m, int32_t n, int64_t lddy, const
     const bool vec = n % 4 == 0 && al16(dy) && lddy % 4 == 0 && (!y || (al16(y) && ldy % 4 == 0 && al16(dz) && lddz % 4 == 0));
     if (vec)
         act_bwd_colsum_kernel<4><<<dim3(chunks, (unsigned)ws_ceil_div(ws_ceil_div(n, 4), 256)), 256, 0, st>>>(
-            dy, y, m, n, lddy, ldy, slope, dz, lddz, partial, chunk);
+            dy, y, m, n, lddy, ldy, slope, dz, lddz, partial, chunk, drop);
     else
         act_bwd_colsum_kernel<1><<<dim3(chunks, (unsigned)ws_ceil_div(n, 256)), 256, 0, st>>>(dy, y, m, n, lddy, ldy, slope, dz, lddz,
-                                                                                              partial, chunk);
+                                                                                              partial, chunk, drop);
     WS_LAUNCH_CHECK();
     if (colsum && chunks > 1) {
         reduce_partials_kernel<<<(unsigned)ws_ceil_div(n, 32), 256, 0, st>>>(partial, n, chunks, colsum);
@@ -1380,7 +1413,20 @@ int ws_gemm_xb_gated_strided(const float* x, int64_t m, int32_t k, int64_t ldx, 
     WS_REQUIRE(!gate_y || ldg >= n, "gate leading dimension too small");
     WS_REQUIRE(!mask || ldm >= n, "mask leading dimension too small");
     return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
-                        b_row_stride, b_col_stride, XbGate{gate_y, ldg, gate_slope, mask, ldm, mask_scale});
+                        b_row_stride, b_col_stride, XbGate{gate_y, ldg, gate_slope, mask, ldm, mask_scale, WsDrop{}, 0});
+}
+
+int ws_gemm_xb_dropout_strided(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride,
+                               int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
+                               int32_t act, float slope, float drop_p, uint64_t drop_seed, float* y, int64_t ldy, void* scratch,
+                               int64_t scratch_bytes, void* stream)
+{
+    WS_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "bad drop probability %g", (double)drop_p);
+    XbGate gate{};
+    gate.drop = ws_drop_args(drop_p, drop_seed);
+    gate.dn = n;
+    return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
+                        b_row_stride, b_col_stride, gate);
 }
 
 int ws_gemm_xb(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n, float* y, int64_t ldy,

@@ -150,30 +150,21 @@ int ws_softmax_ce_bwd(const float* logits, int64_t n, int32_t c, int64_t ldl, co
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned long long i)
-{
-    unsigned long long z = seed + i * 0x9E3779B97F4A7C15ull;      // splitmix64 finaliser
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (unsigned)(z >> 32);
-}
-
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ in, int64_t n, unsigned threshold, float scale,
                                                              unsigned long long seed, float* __restrict__ out)
 {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 v = reinterpret_cast<const float4*>(in)[i];
-        v.x = drop_hash(seed, 4 * i + 0) >= threshold ? v.x * scale : 0.0f;
-        v.y = drop_hash(seed, 4 * i + 1) >= threshold ? v.y * scale : 0.0f;
-        v.z = drop_hash(seed, 4 * i + 2) >= threshold ? v.z * scale : 0.0f;
-        v.w = drop_hash(seed, 4 * i + 3) >= threshold ? v.w * scale : 0.0f;
+        v.x = ws_drop_hash(seed, 4 * i + 0) >= threshold ? v.x * scale : 0.0f;
+        v.y = ws_drop_hash(seed, 4 * i + 1) >= threshold ? v.y * scale : 0.0f;
+        v.z = ws_drop_hash(seed, 4 * i + 2) >= threshold ? v.z * scale : 0.0f;
+        v.w = ws_drop_hash(seed, 4 * i + 3) >= threshold ? v.w * scale : 0.0f;
         reinterpret_cast<float4*>(out)[i] = v;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        out[i] = drop_hash(seed, i) >= threshold ? in[i] * scale : 0.0f;
+        out[i] = ws_drop_hash(seed, i) >= threshold ? in[i] * scale : 0.0f;
     }
 }
 
@@ -185,10 +176,8 @@ extern "C" int ws_dropout_apply(const float* in, int64_t n, float p, uint64_t se
     if (n == 0) return WS_OK;
     WS_REQUIRE(in && out, "NULL argument");
     WS_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0, "16-byte aligned tensors expected");
-    const double t = (double)p * 4294967296.0;
-    const unsigned threshold = t >= 4294967295.0 ? 4294967295u : (unsigned)t;      // drop when hash < p * 2^32
-    dropout_apply_kernel<<<ws_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(in, n, threshold, 1.0f / (1.0f - p),
-                                                                                  (unsigned long long)seed, out);
+    const WsDrop d = ws_drop_args(p, (unsigned long long)seed);                     // drop when hash < p * 2^32
+    dropout_apply_kernel<<<ws_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(in, n, d.threshold, d.scale, d.seed, out);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }

@@ -104,4 +104,31 @@ __device__ __forceinline__ float ws_wave_sum(float v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// nn.Dropout's keep decision as a pure function of (seed, element index): splitmix64 finaliser, upper 32 bits; an element is
+// dropped when the hash is below p * 2^32 (loss.hip: ws_dropout_apply; the fused forms in gemm.hip recompute the same bits)
+struct WsDrop {
+    unsigned long long seed;
+    unsigned threshold;
+    float scale;           // 1 / (1 - p)
+    int on;
+};
+__device__ __forceinline__ unsigned ws_drop_hash(unsigned long long seed, unsigned long long i)
+{
+    unsigned long long z = seed + i * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (unsigned)(z >> 32);
+}
+__device__ __forceinline__ float ws_drop1(float v, const WsDrop& d, unsigned long long i)
+{
+    return ws_drop_hash(d.seed, i) >= d.threshold ? v * d.scale : 0.0f;
+}
+inline WsDrop ws_drop_args(float p, unsigned long long seed)
+{
+    const double t = (double)p * 4294967296.0;
+    return WsDrop{seed, t >= 4294967295.0 ? 4294967295u : (unsigned)t, 1.0f / (1.0f - p), p > 0.0f ? 1 : 0};
+}
+
 #endif

@@ -57,7 +57,8 @@ class UpUnaryDesc(C.Structure):
     _fields_ = [("xc", _vp), ("nc", _i64), ("c_up", _i32), ("skip", _vp), ("nf", _i64), ("c_skip", _i32),
                 ("ups", _vp), ("h_up", _i32), ("t_offsets", _vp), ("t_pairs", _vp),
                 ("w", _vp), ("ldw", _i64), ("b", _vp), ("out_dim", _i32), ("relu", _i32), ("slope", _f32),
-                ("yc", _vp), ("out", _vp), ("dout", _vp), ("dxc", _vp), ("dskip", _vp), ("dw", _vp), ("db", _vp)]
+                ("yc", _vp), ("out", _vp), ("dout", _vp), ("dxc", _vp), ("dskip", _vp), ("dw", _vp), ("db", _vp),
+                ("drop_p", _f32), ("drop_seed", C.c_uint64)]
 
 
 _GATES_SET = False
@@ -288,7 +289,7 @@ class _UpUnaryFn(torch.autograd.Function):
     """nearest_upsample -> concat(skip) -> unary as up(x @ Wx^T) + skip @ Ws^T (architectures.py:339-343)"""
 
     @staticmethod
-    def forward(ctx, xc, skip, w, b, ups, table, relu):
+    def forward(ctx, xc, skip, w, b, ups, table, relu, drop_p=0.0, drop_seed=0):
         lib = _bind()
         dev = xc.device
         xc, skip, w = xc.contiguous(), skip.contiguous(), w.contiguous()
@@ -302,12 +303,13 @@ class _UpUnaryFn(torch.autograd.Function):
         d.ups, d.h_up = ups.data_ptr(), ups.shape[1]
         d.w, d.ldw, d.b, d.out_dim, d.relu, d.slope = w.data_ptr(), w.stride(0), _p(b), out_dim, 1 if relu else 0, 0.1
         d.yc, d.out = yc.data_ptr(), out.data_ptr()
+        d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)      # the droplayer in front of the head, on this step's epilogue
         nbytes = lib.ws_upunary_fwd_scratch_bytes(C.byref(d))
         if nbytes < 0:
             check(1)
         scratch = _scratch(nbytes, dev)
         check(lib.ws_upunary_fwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
-        ctx.table, ctx.relu = table, relu
+        ctx.table, ctx.relu, ctx.drop = table, relu, (float(drop_p), int(drop_seed))
         ctx.save_for_backward(xc, skip, w, b, ups, out)
         return out
 
@@ -326,6 +328,7 @@ class _UpUnaryFn(torch.autograd.Function):
         d.t_offsets, d.t_pairs = ctx.table.offsets.data_ptr(), ctx.table.pairs.data_ptr()
         d.w, d.ldw, d.b, d.out_dim, d.relu, d.slope = w.data_ptr(), w.stride(0), _p(b), out_dim, 1 if ctx.relu else 0, 0.1
         d.out, d.dout = out.data_ptr(), dout.data_ptr()
+        d.drop_p, d.drop_seed = ctx.drop
         dxc, dskip = torch.empty_like(xc), torch.empty_like(skip)
         dw = torch.empty_like(w)
         db = torch.empty_like(b) if b is not None else None
@@ -335,7 +338,7 @@ class _UpUnaryFn(torch.autograd.Function):
             check(1)
         scratch = _scratch(nbytes, dev)
         check(lib.ws_upunary_bwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
-        return dxc, dskip, dw, db, None, None, None
+        return dxc, dskip, dw, db, None, None, None, None, None
 
 
 def upunary_eligible(x, skip, unary):
@@ -344,8 +347,14 @@ def upunary_eligible(x, skip, unary):
             and unary.out_dim % 32 == 0 and x.shape[0] > 0 and skip.shape[0] >= MIN_ROWS)
 
 
-def upunary(x, skip, unary, ups):
+def upunary(x, skip, unary, ups, drop=None):
+    """drop = (p, seed): nn.Dropout(p) applied to the step's output inside its last epilogue (the bits of ops.dropout with that
+    seed); needs the unary's LeakyReLU"""
     ups = ups.contiguous()
     ups = ups if ups.dtype == torch.int64 else ups.to(torch.int64)
     table = ops.col0_table(ups, x.shape[0]) if torch.is_grad_enabled() else None      # (only the backward reads it)
+    if drop is not None:
+        if unary.no_relu:
+            raise _lib.WeasalHipError("upunary: the fused dropout follows the unary's LeakyReLU")
+        return _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, True, float(drop[0]), int(drop[1]))
     return _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, not unary.no_relu)
