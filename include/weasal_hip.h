@@ -533,6 +533,9 @@ typedef struct ws_kpblock {
                                             the gather stops at the reach of the kernel points (ws_kpconv_gather_fwd_ex) */
     int32_t infer;                       /* 1: forward only -- no backward will follow: `wf` may be NULL and layers the fused
                                             forward kernel covers (ws_kpconv_layer_fwd_fused) run as one launch */
+    const float* dfeat_add;              /* backward, optional [ns,in_dim]: a second gradient of `feat` (the decoder's skip
+                                            connection reads the same tensor, architectures.py:339-341), summed into dfeat by
+                                            the kernel that writes the shortcut's share instead of by a pass of its own */
 } ws_kpblock;
 
 int64_t ws_kpblock_fwd_scratch_bytes(const ws_kpblock* d);

@@ -113,3 +113,51 @@ def test_kpblock_rejects_unsupported_shapes_loudly(gpu):
     assert lib.ws_kpblock_fwd_scratch_bytes(C.byref(d)) == -1 and b"multiples of 4" in lib.ws_last_error()
     d.conv_out = d.out_dim = 8
     assert lib.ws_kpblock_fwd_scratch_bytes(C.byref(d)) > 0
+
+
+@pytest.mark.gpu
+def test_skip_gradients_summed_inside_the_strided_block(monkeypatch):
+    """an encoder tensor read by the next strided block and by the decoder's skip connection: with the slots (fused.SkipSlot)
+    the decoder's share is summed into the block's input gradient by the pool backward's store; without them autograd adds
+    the two.  Same gradients (the association of the three-term sum differs: 1e-6), every level's slot used, and a backward
+    whose nodes run in the other order (the block first: torch.autograd.grad on the encoder alone, then the tap) stays exact"""
+    from weasal_amd import config as wcfg, fused, pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    dev = torch.device("cuda:0")
+    cfg = wcfg.Vaihingen3DPLConfig()
+    wl = synthetic.WORKLOADS["vaihingen"]
+    pts, feats, labels, lens = synthetic.make_inputs(11, 2, wl["points"], wl["radius"], cfg.in_features_dim)
+
+    def run(on):
+        monkeypatch.setattr(fused, "SKIP_SLOTS", on)
+        np.random.seed(1)
+        torch.manual_seed(1)
+        net = KPFCNN(cfg, np.arange(9), []).to(dev).train()
+        np.random.seed(2)
+        batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev),
+                                    torch.from_numpy(labels).to(dev), lens, wl["limits"])
+        torch.manual_seed(5)
+        hits = fused.skip_slot_hits
+        out = net(batch, cfg)
+        loss = net.loss(out, batch.labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}, \
+            fused.skip_slot_hits - hits
+
+    oa, ga, ha = run(True)
+    ob, gb, hb = run(False)
+    assert ha == cfg.num_layers - 1 and hb == 0
+    assert torch.equal(oa, ob)
+    for k in ga:
+        scale = float(gb[k].abs().max()) + 1e-30
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale, k
+
+    # the other order: the block's backward before the tap's
+    slot = fused.SkipSlot()
+    slot.armed = True
+    x = torch.randn(1000, 32, device=dev, requires_grad=True)
+    tapped = fused.skip_tap(x, slot)
+    slot.taken = True                          # what a block backward that found the slot empty leaves behind
+    (g,) = torch.autograd.grad(tapped.sum(), x)
+    assert torch.equal(g, torch.ones_like(x)) and slot.grad is None

@@ -153,10 +153,16 @@ class KPFCNN(nn.Module):
             ops.clear_table_cache()          # transposed tables belong to one batch
         x = batch.features.clone().detach()
         skips = []
+        slots = []
         for block_i, block_op in enumerate(self.encoder_blocks):
+            slot = None
             if block_i in self.encoder_skips:
                 skips.append(x)
+                slot = fused.SkipSlot()      # (armed by the strided block call if it is one: fused.resnetb_block)
+                slots.append(slot)
+            batch.skip_slot = slot
             x = block_op(x, batch)
+            batch.skip_slot = None
             if block_i == 0 and self.feature_dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[1] % 32 == 0:
                 x = x.to(torch.bfloat16)     # the 3-channel input layer ran in f32; bf16 rows from here on
         nd = len(self.decoder_blocks)
@@ -174,11 +180,11 @@ class KPFCNN(nn.Module):
                     # the same keep decisions as ops.dropout (same seed draw), no pass of its own in either direction
                     drop = (float(self.dropout), int(torch.randint(0, 1 << 62, (1,)).item()))
                     dropped = True
-                x = self._fused_upsample_unary(x, skips.pop(), block_op, nxt, batch, drop)
+                x = self._fused_upsample_unary(x, fused.skip_tap(skips.pop(), slots.pop()), block_op, nxt, batch, drop)
                 block_i += 2
                 continue
             if block_i in self.decoder_concats:
-                x = torch.cat([x, skips.pop()], dim=1)
+                x = torch.cat([x, fused.skip_tap(skips.pop(), slots.pop())], dim=1)
             x = block_op(x, batch)
             block_i += 1
         if self.dropout and not dropped:

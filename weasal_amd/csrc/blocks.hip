@@ -254,7 +254,10 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         if (d->w1) { WS_HIP(hipMemsetAsync(d->dw1, 0, sizeof(float) * (size_t)d->conv_in * d->in_dim, st)); if (d->db1) WS_HIP(hipMemsetAsync(d->db1, 0, sizeof(float) * d->conv_in, st)); }
         if (d->w2) { WS_HIP(hipMemsetAsync(d->dw2, 0, sizeof(float) * (size_t)d->out_dim * d->conv_out, st)); if (d->db2) WS_HIP(hipMemsetAsync(d->db2, 0, sizeof(float) * d->out_dim, st)); }
         if (d->w2 && d->ws) WS_HIP(hipMemsetAsync(d->dws, 0, sizeof(float) * (size_t)d->out_dim * d->in_dim, st));
-        if (d->dfeat && ns > 0) WS_HIP(hipMemsetAsync(d->dfeat, 0, sizeof(float) * (size_t)ns * d->in_dim, st));
+        if (d->dfeat && ns > 0) {
+            if (d->dfeat_add) WS_HIP(hipMemcpyAsync(d->dfeat, d->dfeat_add, sizeof(float) * (size_t)ns * d->in_dim, hipMemcpyDeviceToDevice, st));
+            else WS_HIP(hipMemsetAsync(d->dfeat, 0, sizeof(float) * (size_t)ns * d->in_dim, st));
+        }
         return WS_OK;
     }
     bool gated2 = false;
@@ -269,6 +272,7 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         return WS_OK;
     };
     const float* sc_res = nullptr;          // the shortcut's gradient w.r.t. feat rows [ns,in_dim]
+    bool added = false;                     // dfeat_add already summed in (by the pool backward's store)
     const float* gin = d->dout;             // gradient entering the convolution's activation
     const float* yconv = d->out;
     if (d->w2) {
@@ -290,8 +294,11 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
             if (d->strided) {
                 WS_REQUIRE(d->t_offsets && d->t_pairs, "strided block backward needs the transposed table");
                 if (arg_bytes(d))
+                {
                     WS_TRY(ws_priv_max_pool_bwd_u8(dsc, reinterpret_cast<const uint8_t*>(d->arg), nq, d->h, d->in_dim, d->t_offsets,
-                                                   d->t_pairs, ns, dfsc, ws_block_pool_order ? d->order_s : nullptr, st));
+                                                   d->t_pairs, ns, dfsc, ws_block_pool_order ? d->order_s : nullptr, d->dfeat_add, st));
+                    added = d->dfeat_add != nullptr;
+                }
                 else
                     WS_TRY(ws_max_pool_bwd(dsc, d->arg, nq, d->h, d->in_dim, d->t_offsets, d->t_pairs, ns, dfsc, st));
                 sc_res = dfsc;
@@ -348,6 +355,12 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     } else if (d->dfeat && sc_res) {
         const int64_t n4 = ns * d->in_dim / 4;
         add_rows_kernel<<<ws_grid(n4, 256), 256, 0, st>>>(d->dfeat, sc_res, n4);
+        WS_LAUNCH_CHECK();
+    }
+    if (d->dfeat && d->dfeat_add && !added) {       // (block shapes without a strided shortcut: a pass of its own)
+        WS_REQUIRE(d->in_dim % 4 == 0, "dfeat_add needs in_dim %% 4 == 0");
+        const int64_t n4 = ns * d->in_dim / 4;
+        add_rows_kernel<<<ws_grid(n4, 256), 256, 0, st>>>(d->dfeat, d->dfeat_add, n4);
         WS_LAUNCH_CHECK();
     }
     return join();

@@ -131,8 +131,9 @@ __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restri
                                                                 int h, int c, const int32_t* __restrict__ t_offsets,
                                                                 const int32_t* __restrict__ t_pairs, int64_t ns,
                                                                 T* __restrict__ dx, const int32_t* __restrict__ order = nullptr,
-                                                                int ilv = 0)
+                                                                int ilv = 0, const T* __restrict__ add = nullptr)
 {
+    // add (same shape as dx, or NULL): a second gradient of the same rows, summed into the store -- dx = pool gradient + add
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane % G, slot = lane / G;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restri
                     if (a.w == col) acc.w += g.w;
                 }
             }
+            if (add) { const float4 o = ld4(add + s * c + ch); acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
             st4(dx + s * c + ch, acc);
         }
     }
@@ -321,15 +323,15 @@ int max_pool_fwd_u8_impl(const float* x, int64_t ns, int32_t c, const int64_t* i
 }
 
 int max_pool_bwd_u8_impl(const float* dy, const uint8_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
-                         const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order, hipStream_t st)
+                         const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order, hipStream_t st, const float* add = nullptr)
 {
     (void)nq;
     if (ns == 0) return WS_OK;
     const int ilv = order ? ws_pool_interleave : 0;       // (only with a spatial order is a neighbouring group a neighbouring place)
-    if (c <= 32) max_pool_bwd_vec_kernel<8, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 8), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
-    else if (c <= 64) max_pool_bwd_vec_kernel<16, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 4), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
-    else if (c <= 128) max_pool_bwd_vec_kernel<32, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 2), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
-    else max_pool_bwd_vec_kernel<64, float, uint8_t><<<pool_grid(ns, ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    if (c <= 32) max_pool_bwd_vec_kernel<8, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 8), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add);
+    else if (c <= 64) max_pool_bwd_vec_kernel<16, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 4), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add);
+    else if (c <= 128) max_pool_bwd_vec_kernel<32, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 2), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add);
+    else max_pool_bwd_vec_kernel<64, float, uint8_t><<<pool_grid(ns, ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add);
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
@@ -448,9 +450,9 @@ int ws_priv_max_pool_fwd_u8(const float* x, int64_t ns, int32_t c, const int64_t
 }
 
 int ws_priv_max_pool_bwd_u8(const float* dy, const uint8_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
-                            const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order_s, void* stream)
+                            const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order_s, const float* add, void* stream)
 {
-    return max_pool_bwd_u8_impl(dy, arg, nq, h, c, t_offsets, t_pairs, ns, dx, order_s, (hipStream_t)stream);
+    return max_pool_bwd_u8_impl(dy, arg, nq, h, c, t_offsets, t_pairs, ns, dx, order_s, (hipStream_t)stream, add);
 }
 
 }  // extern "C"

@@ -46,7 +46,8 @@ static inline int64_t ws_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b
 extern "C" int ws_priv_max_pool_fwd_u8(const float* x, int64_t ns, int32_t c, const int64_t* inds, int64_t nq, int32_t h, float* out,
                                        uint8_t* arg, const int32_t* order_q, void* stream);
 extern "C" int ws_priv_max_pool_bwd_u8(const float* dy, const uint8_t* arg, int64_t nq, int32_t h, int32_t c, const int32_t* t_offsets,
-                                       const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order_s, void* stream);
+                                       const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order_s, const float* add,
+                                       void* stream);        // add: NULL or [ns, c] summed into dx
 
 // grid size for wave-per-item / grid-stride kernels: enough workgroups to fill 256 CUs a few
 // times over, never more than the work.

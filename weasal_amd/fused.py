@@ -49,7 +49,7 @@ class KPBlockDesc(C.Structure):
                 ("w1", _vp), ("b1", _vp), ("wk", _vp), ("bk", _vp), ("w2", _vp), ("b2", _vp), ("ws", _vp), ("bs", _vp),
                 ("feat", _vp), ("x1", _vp), ("wf", _vp), ("x2", _vp), ("pooled", _vp), ("arg", _vp), ("out", _vp),
                 ("dout", _vp), ("dfeat", _vp), ("dw1", _vp), ("db1", _vp), ("dwk", _vp), ("dbk", _vp), ("dw2", _vp),
-                ("db2", _vp), ("dws", _vp), ("timed", _i32), ("rows_sorted", _i32), ("infer", _i32)]
+                ("db2", _vp), ("dws", _vp), ("timed", _i32), ("rows_sorted", _i32), ("infer", _i32), ("dfeat_add", _vp)]
 
 
 class UpUnaryDesc(C.Structure):
@@ -108,7 +108,7 @@ def _scratch(nbytes, device):
 class _Geom:
     """geometry + widths of one block call (plain Python object carried through the autograd node)"""
     __slots__ = ("q_pts", "s_pts", "inds", "kp", "extent", "order_q", "order_s", "grid", "table", "in_dim", "conv_in",
-                 "conv_out", "out_dim", "strided", "slope", "has", "rows_sorted", "infer")
+                 "conv_out", "out_dim", "strided", "slope", "has", "rows_sorted", "infer", "skip_slot")
 
     def fill(self, d):
         d.q_pts, d.nq = self.q_pts.data_ptr(), self.q_pts.shape[0]
@@ -130,6 +130,41 @@ class _Geom:
 
 def _al(n):
     return (n + 63) // 64 * 64
+
+
+class SkipSlot:
+    """An encoder tensor read twice -- by the strided block that follows it and, through the skip connection, by a decoder
+    step (architectures.py:330-341) -- gets two gradients, which autograd adds in a pass of its own (3 x 205 MB at level 0).
+    With a slot the decoder's share is parked here by `skip_tap` and the strided block's backward sums it into the gradient
+    it writes anyway (ws_kpblock.dfeat_add).  Whichever of the two backward nodes runs second finds out from the slot, so
+    the result does not depend on the engine's order: if the block's backward came first, the tap returns its gradient the
+    ordinary way."""
+    __slots__ = ("grad", "armed", "taken")
+
+    def __init__(self):
+        self.grad, self.armed, self.taken = None, False, False
+
+
+class _SkipTap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        slot = ctx.slot
+        if slot.armed and not slot.taken and slot.grad is None:
+            slot.grad = g
+            return None, None
+        return g, None
+
+
+def skip_tap(x, slot):
+    """the skip connection's view of an encoder tensor whose other reader is an armed strided block call"""
+    if slot is None or not slot.armed or not torch.is_grad_enabled() or not x.requires_grad:
+        return x
+    return _SkipTap.apply(x, slot)
 
 
 class _KPBlockFn(torch.autograd.Function):
@@ -197,6 +232,18 @@ class _KPBlockFn(torch.autograd.Function):
         d.out, d.dout = out.data_ptr(), dout.data_ptr()
         dfeat = torch.empty_like(feat) if need[0] else None
         d.dfeat = _p(dfeat)
+        slot = getattr(g, "skip_slot", None)
+        extra = None
+        if slot is not None:
+            slot.taken = True                              # (a tap that runs after this point returns its gradient itself)
+            extra, slot.grad = slot.grad, None
+            if extra is not None and (dfeat is None or extra.shape != feat.shape or extra.dtype != torch.float32):
+                raise _lib.WeasalHipError("skip gradient %s does not match the block input %s" % (tuple(extra.shape), tuple(feat.shape)))
+            if extra is not None:
+                extra = extra.contiguous()
+                global skip_slot_hits
+                skip_slot_hits += 1
+        d.dfeat_add = _p(extra)
         # parameter gradients: one tensor each (autograd adopts an unshared, contiguous gradient as .grad without a copy)
         grads = [None if p is None else torch.empty_like(p) for p in (w1, b1, wk, bk, w2, b2, wsc)]
         d.dw1, d.db1, d.dwk, d.dbk, d.dw2, d.db2, d.dws = [_p(t) for t in grads]
@@ -208,6 +255,10 @@ class _KPBlockFn(torch.autograd.Function):
         dw1, db1, dwk, dbk, dw2, db2, dws = grads
         dbs = db2.clone() if (bsc is not None and db2 is not None) else None          # the shortcut bias sees the same dz as b2
         return dfeat, dw1, db1, dwk, dbk, dw2, db2, dws, dbs, None
+
+
+skip_slot_hits = 0      # (tests) skip gradients summed inside a strided block's backward so far
+SKIP_SLOTS = os.environ.get("WEASAL_SKIP_SLOTS", "1") != "0"      # A/B switch: 0 = autograd adds the two gradients of a skip tensor
 
 
 def _conv_ok(conv, x):
@@ -231,6 +282,7 @@ def _geometry(conv, q_pts, s_pts, inds, strided):
     # (the block calls know the slab form of the grid backward only: rows up to 128 neighbours)
     g.grid = grid if (grid is not None and grid.ns == ns and grid.max_count <= ops.GRID_NARROW_MAX) else None
     g.table = None
+    g.skip_slot = None
     g.strided = strided
     g.rows_sorted = ops.rows_cutoff_pays(g.inds, conv.radius)      # searched with the deformable radius: stop at the kernel's reach
     g.infer = not torch.is_grad_enabled()      # a forward pass nobody will differentiate (the testers' loops run under no_grad)
@@ -271,6 +323,10 @@ def resnetb_block(block, x, batch, q_pts, s_pts, inds):
     conv = block.KPConv
     strided = 'strided' in block.block_name
     g = _geometry(conv, q_pts, s_pts, inds, strided)
+    slot = getattr(batch, "skip_slot", None) if strided else None
+    if slot is not None and SKIP_SLOTS and torch.is_grad_enabled() and x.requires_grad and x.dtype == torch.float32:
+        g.skip_slot = slot
+        slot.armed = True
     g.in_dim, g.conv_in, g.conv_out, g.out_dim = block.in_dim, conv.in_channels, conv.out_channels, block.out_dim
     g.slope = 0.1
     if torch.is_grad_enabled() and (g.grid is None or strided):       # (only a backward reads the table)
