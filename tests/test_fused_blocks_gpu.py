@@ -161,3 +161,45 @@ def test_skip_gradients_summed_inside_the_strided_block(monkeypatch):
     slot.taken = True                          # what a block backward that found the slot empty leaves behind
     (g,) = torch.autograd.grad(tapped.sum(), x)
     assert torch.equal(g, torch.ones_like(x)) and slot.grad is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nc,nf,c_up,c_skip,out_dim,drop", [(900, 5003, 64, 32, 32, 0.0), (37, 300, 256, 128, 128, 0.5), (4000, 40001, 128, 64, 64, 0.5)])
+def test_decoder_step_gathers_the_upsampled_rows_in_its_epilogue(gpu, nc, nf, c_up, c_skip, out_dim, drop):
+    """ws_upunary_fwd with the nearest-upsampled rows read by the last product's epilogue (yc[ups[r, 0]] as a gathered
+    residual; shadow indices add nothing) against the form that writes them out first (ws_closest_pool_fwd): same bits, with
+    and without the fused dropout, rows-on-lanes and split-K products; and against upsample -> concat -> unary in float64"""
+    import ctypes as C
+    from weasal_amd import _lib, fused
+    from weasal_amd.blocks import UnaryBlock
+    from weasal_amd import config as wcfg
+    lib = fused._bind()
+    torch.manual_seed(nc)
+    cfg = wcfg.Vaihingen3DPLConfig()
+    unary = UnaryBlock(c_up + c_skip, out_dim, False, 0).to(gpu)
+    with torch.no_grad():
+        unary.batch_norm.bias.normal_()
+    x = torch.randn(nc, c_up, device=gpu)
+    skip = torch.randn(nf, c_skip, device=gpu)
+    ups = torch.randint(0, nc, (nf, 3), device=gpu)
+    ups[::17, 0] = nc                                           # shadow rows: the zero feature (blocks.py:80-92)
+    flag = C.c_int.in_dll(lib, "ws_block_gather_residual")
+    outs = []
+    try:
+        for v in (0, 1):
+            flag.value = v
+            with torch.no_grad():
+                outs.append(fused.upunary(x, skip, unary, ups, (drop, 424242) if drop else None))
+            torch.cuda.synchronize()
+    finally:
+        flag.value = 1
+    assert torch.equal(outs[0], outs[1])
+    xp = torch.cat([x, torch.zeros(1, c_up, device=gpu)]).double()
+    want = torch.nn.functional.leaky_relu(torch.cat([xp[ups[:, 0]], skip.double()], 1) @ unary.mlp.weight.double().t()
+                                          + unary.batch_norm.bias.double(), 0.1)
+    got = outs[1].double()
+    if drop:
+        keep = got != 0
+        assert 0.4 < float(keep.float().mean()) < 0.6
+        want = torch.where(keep, want / (1 - drop), torch.zeros_like(want))
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())

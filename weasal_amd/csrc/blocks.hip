@@ -12,6 +12,7 @@
 
 // diagnostics switch (WEASAL_BLOCK_GATES=0): activation backward as separate passes instead of epilogue / store gates
 extern "C" int ws_block_gates = 1;
+extern "C" int ws_block_gather_residual = 1;   // decoder step: 1 = the upsampled rows are gathered by the last epilogue, 0 = written out first (A/B)
 // Diagnostics (WEASAL_BLOCK_SIDE_ROWS=<rows>): blocks with fewer query rows than this run their weight-gradient products
 // (dW = X^T dZ: leaves of the backward, nothing on the chain to dX waits for them) on a side stream next to the dX chain.
 // Default 0 = off: measured on the DALES step the deep levels' products are bound by the matrix cores and by their
@@ -390,8 +391,14 @@ int upunary_fwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
     if (d->nc > 0)
         WS_TRY(ws_gemm_xb_epilogue_strided(d->xc, d->nc, d->c_up, d->c_up, d->w, 1, d->ldw, d->out_dim, nullptr, nullptr, 0, 0, 0.0f, d->yc,
                                            d->out_dim, tmp, tmp_bytes, st));
+    if (ws_block_gather_residual && d->nc > 0)
+        // nearest upsampling (closest_pool) read by the epilogue: out row r adds yc[ups[r, 0]] (nothing for the shadow index);
+        // the droplayer in front of the head (drop_p > 0) rides on the same epilogue
+        return ws_priv_gemm_xb_ex(d->skip, d->nf, d->c_skip, d->c_skip, d->w + d->c_up, 1, d->ldw, d->out_dim, d->b, d->yc, d->out_dim,
+                                  d->ups, d->h_up, d->nc, d->relu ? 1 : 0, d->slope, d->drop_p, d->drop_seed, d->out, d->out_dim, tmp,
+                                  tmp_bytes, st);
     WS_TRY(ws_closest_pool_fwd(d->yc, d->nc, d->out_dim, d->ups, d->nf, d->h_up, up, st));
-    if (d->drop_p > 0.0f)       // the droplayer in front of the head rides on this epilogue
+    if (d->drop_p > 0.0f)
         return ws_gemm_xb_dropout_strided(d->skip, d->nf, d->c_skip, d->c_skip, d->w + d->c_up, 1, d->ldw, d->out_dim, d->b, up, d->out_dim,
                                           1, d->slope, d->drop_p, d->drop_seed, d->out, d->out_dim, tmp, tmp_bytes, st);
     return ws_gemm_xb_epilogue_strided(d->skip, d->nf, d->c_skip, d->c_skip, d->w + d->c_up, 1, d->ldw, d->out_dim, d->b, up, d->out_dim,

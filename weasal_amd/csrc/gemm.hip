@@ -36,7 +36,19 @@ struct XbGate {
     const float* y; int64_t ld; float slope;
     const uint8_t* mask; int64_t ldm; float mscale;
     WsDrop drop; int64_t dn;
+    // rrows (NULL = none): the residual row of output row r is residual[rrows[r * rld]] instead of residual[r] -- a row gather
+    // (closest_pool / nearest upsampling, blocks.py:80-92) read by the epilogue instead of written out first; indices outside
+    // [0, rn) are the shadow row: zeros
+    const int64_t* rrows; int64_t rld; int64_t rn;
 };
+// first float of the residual row of output row `row` (NULL: the shadow row, or no residual)
+__device__ __forceinline__ const float* xb_res_row(const float* residual, int64_t ldr, const XbGate& g, int64_t row)
+{
+    if (!residual) return nullptr;
+    if (!g.rrows) return residual + row * ldr;
+    const int64_t i = g.rrows[row * g.rld];
+    return (i >= 0 && i < g.rn) ? residual + i * ldr : nullptr;
+}
 __device__ __forceinline__ void xb_gate4(float4& v, const XbGate& g, int64_t row, int col)
 {
     if (g.y) {
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_xb_kernel(const float* __restrict__ 
             const int64_t row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < m && col < n) {
                 float v = acc[i][r] + bv;
-                if (residual) v += residual[row * ldr + col];
+                if (residual) { const float* rr_ = xb_res_row(residual, ldr, gate, row); if (rr_) v += rr_[col]; }
                 if (act) v = v > 0.0f ? v : v * slope;
                 y[row * ldy + col] = xb_gate1(v, gate, row, col);
             }
@@ -187,7 +199,7 @@ __device__ __forceinline__ void xb_rows_epilogue(const f32x16 (&acc)[NT], int64_
     const bool live = row < m;
     const int64_t rr = live ? row : m - 1;
     float* yrow = y + rr * ldy;
-    const float* rrow = residual ? residual + rr * ldr : nullptr;
+    const float* rrow = xb_res_row(residual, ldr, gate, rr);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         float4 v[4];
@@ -269,7 +281,10 @@ __device__ __forceinline__ void xb_rows_epilogue_staged(const f32x16 (&acc)[NT],
             rr[p] = row < m ? row : m - 1;
             v[p] = *reinterpret_cast<const float4*>(&stage[rl * XB_STAGE_LD + 4 * c4]);
             rq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (residual) rq[p] = *reinterpret_cast<const float4*>(residual + rr[p] * ldr + colc);
+            if (residual) {
+                const float* rrow = xb_res_row(residual, ldr, gate, rr[p]);
+                if (rrow) rq[p] = *reinterpret_cast<const float4*>(rrow + colc);
+            }
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -648,8 +663,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
         }
         if (bias) { const float4 bq = *reinterpret_cast<const float4*>(bias + c); v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w; }
         if (residual) {
-            const float4 rq = *reinterpret_cast<const float4*>(residual + r * ldr + c);
-            v.x += rq.x; v.y += rq.y; v.z += rq.z; v.w += rq.w;
+            const float* rrow = xb_res_row(residual, ldr, gate, r);
+            if (rrow) {
+                const float4 rq = *reinterpret_cast<const float4*>(rrow + c);
+                v.x += rq.x; v.y += rq.y; v.z += rq.z; v.w += rq.w;
+            }
         }
         if (act) {
             v.x = v.x > 0.0f ? v.x : v.x * slope; v.y = v.y > 0.0f ? v.y : v.y * slope;
@@ -1413,7 +1431,7 @@ int ws_gemm_xb_gated_strided(const float* x, int64_t m, int32_t k, int64_t ldx, 
     WS_REQUIRE(!gate_y || ldg >= n, "gate leading dimension too small");
     WS_REQUIRE(!mask || ldm >= n, "mask leading dimension too small");
     return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
-                        b_row_stride, b_col_stride, XbGate{gate_y, ldg, gate_slope, mask, ldm, mask_scale, WsDrop{}, 0});
+                        b_row_stride, b_col_stride, XbGate{gate_y, ldg, gate_slope, mask, ldm, mask_scale, WsDrop{}, 0, nullptr, 0, 0});
 }
 
 int ws_gemm_xb_dropout_strided(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride,
@@ -1425,6 +1443,23 @@ int ws_gemm_xb_dropout_strided(const float* x, int64_t m, int32_t k, int64_t ldx
     XbGate gate{};
     gate.drop = ws_drop_args(drop_p, drop_seed);
     gate.dn = n;
+    return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
+                        b_row_stride, b_col_stride, gate);
+}
+
+// private to the library (ws_common.h): the strided product with the whole epilogue menu -- dropout (drop_p > 0) and / or a
+// gathered residual (res_rows != NULL: row r adds residual[res_rows[r * res_rows_ld]], indices outside [0, res_nrows) add nothing)
+int ws_priv_gemm_xb_ex(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride, int64_t b_col_stride,
+                       int32_t n, const float* bias, const float* residual, int64_t ldr, const int64_t* res_rows, int64_t res_rows_ld,
+                       int64_t res_nrows, int32_t act, float slope, float drop_p, uint64_t drop_seed, float* y, int64_t ldy,
+                       void* scratch, int64_t scratch_bytes, void* stream)
+{
+    WS_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "bad drop probability %g", (double)drop_p);
+    WS_REQUIRE(!res_rows || (residual && res_rows_ld >= 1 && res_nrows >= 0), "gathered residual: NULL residual / bad sizes");
+    XbGate gate{};
+    gate.drop = ws_drop_args(drop_p, drop_seed);
+    gate.dn = n;
+    gate.rrows = res_rows; gate.rld = res_rows_ld; gate.rn = res_nrows;
     return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
                         b_row_stride, b_col_stride, gate);
 }

@@ -49,6 +49,11 @@ extern "C" int ws_priv_max_pool_bwd_u8(const float* dy, const uint8_t* arg, int6
                                        const int32_t* t_pairs, int64_t ns, float* dx, const int32_t* order_s, const float* add,
                                        void* stream);        // add: NULL or [ns, c] summed into dx
 
+extern "C" int ws_priv_gemm_xb_ex(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int64_t b_row_stride, int64_t b_col_stride,
+                                  int32_t n, const float* bias, const float* residual, int64_t ldr, const int64_t* res_rows,
+                                  int64_t res_rows_ld, int64_t res_nrows, int32_t act, float slope, float drop_p, uint64_t drop_seed,
+                                  float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream);   // gemm.hip for blocks.hip
+
 // grid size for wave-per-item / grid-stride kernels: enough workgroups to fill 256 CUs a few
 // times over, never more than the work.
 static inline int ws_grid(int64_t items, int per_block, int max_blocks = 256 * 16)

@@ -70,6 +70,7 @@ def _bind():
     if not _GATES_SET:         # diagnostics: WEASAL_BLOCK_GATES=0 = activation backward as separate passes
         C.c_int.in_dll(lib, "ws_block_gates").value = 0 if os.environ.get("WEASAL_BLOCK_GATES", "1") == "0" else 1
         C.c_int.in_dll(lib, "ws_block_fused_infer").value = 1 if FUSED_INFER else 0
+        C.c_int.in_dll(lib, "ws_block_gather_residual").value = 0 if os.environ.get("WEASAL_BLOCK_GATHER_RESIDUAL", "1") == "0" else 1
         C.c_int.in_dll(lib, "ws_block_pool_order").value = 0 if os.environ.get("WEASAL_POOL_ORDER", "1") == "0" else 1
         if "WEASAL_BLOCK_SIDE_ROWS" in os.environ:      # 0 = weight-gradient products on the caller's stream
             C.c_int64.in_dll(lib, "ws_block_side_rows").value = int(os.environ["WEASAL_BLOCK_SIDE_ROWS"])
