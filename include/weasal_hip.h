@@ -533,6 +533,12 @@ typedef struct ws_kpblock {
                                             the gather stops at the reach of the kernel points (ws_kpconv_gather_fwd_ex) */
     int32_t infer;                       /* 1: forward only -- no backward will follow: `wf` may be NULL and layers the fused
                                             forward kernel covers (ws_kpconv_layer_fwd_fused) run as one launch */
+    int32_t dout_pregated;               /* backward: 1 = `dout` already carries this block's output LeakyReLU' (the consumer of
+                                            `out` multiplied it into the gradient it wrote: its gate_dfeat): the block's first
+                                            activation-backward pass is skipped (bias gradients: column sums of dout) */
+    int32_t gate_dfeat;                  /* backward: 1 = write dfeat * LeakyReLU'(feat) -- feat is the activated output of the
+                                            block that produced it, which then runs with dout_pregated; the multiplication
+                                            rides on the kernel that writes dfeat */
     const float* dfeat_add;              /* backward, optional [ns,in_dim]: a second gradient of `feat` (the decoder's skip
                                             connection reads the same tensor, architectures.py:339-341), summed into dfeat by
                                             the kernel that writes the shortcut's share instead of by a pass of its own */
@@ -562,6 +568,8 @@ typedef struct ws_upunary {
      * forward's last epilogue write dropout(out) (keep decision = function of (drop_seed, element index), the bits of
      * ws_dropout_apply) and the backward treat `dout` as the gradient of that dropped tensor.  Needs relu != 0. */
     float drop_p; uint64_t drop_seed;
+    int32_t dout_pregated;               /* as in ws_kpblock: dout already multiplied by LeakyReLU'(out) by the consumer */
+    int32_t gate_dxc;                    /* backward: write dxc * LeakyReLU'(xc) (xc = the activated output of its producer) */
 } ws_upunary;
 
 int64_t ws_upunary_fwd_scratch_bytes(const ws_upunary* d);

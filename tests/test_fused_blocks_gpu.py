@@ -203,3 +203,42 @@ def test_decoder_step_gathers_the_upsampled_rows_in_its_epilogue(gpu, nc, nf, c_
         assert 0.4 < float(keep.float().mean()) < 0.6
         want = torch.where(keep, want / (1 - drop), torch.zeros_like(want))
     assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_gate_links_hand_the_activation_backward_to_the_consumer(monkeypatch):
+    """consecutive block calls (fused.GateLink): the consumer writes its input gradient times LeakyReLU'(input) and the producer
+    skips its first backward pass -- the same products in the same order, so every gradient keeps its bits; the links are
+    taken along the whole encoder and decoder chain, with the skip connections' shares summed before the gate"""
+    from weasal_amd import config as wcfg, fused, pyramid, synthetic
+    from weasal_amd.architectures import KPFCNN
+    dev = torch.device("cuda:0")
+    cfg = wcfg.Vaihingen3DPLConfig()
+    wl = synthetic.WORKLOADS["vaihingen"]
+    pts, feats, labels, lens = synthetic.make_inputs(13, 2, wl["points"], wl["radius"], cfg.in_features_dim)
+
+    def run(on):
+        monkeypatch.setattr(fused, "GATE_LINKS", on)
+        np.random.seed(1)
+        torch.manual_seed(1)
+        net = KPFCNN(cfg, np.arange(9), []).to(dev).train()
+        np.random.seed(2)
+        batch = pyramid.build_batch(cfg, torch.from_numpy(pts).to(dev), torch.from_numpy(feats).to(dev),
+                                    torch.from_numpy(labels).to(dev), lens, wl["limits"])
+        torch.manual_seed(5)
+        hits = fused.gate_link_hits
+        out = net(batch, cfg)
+        loss = net.loss(out, batch.labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None}, \
+            fused.gate_link_hits - hits
+
+    oa, ga, ha = run(True)
+    ob, gb, hb = run(False)
+    n_enc = len([b for b in cfg.architecture if 'upsample' not in b and 'unary' not in b])
+    assert hb == 0 and ha >= n_enc - 1 + 3, (ha, n_enc)
+    assert torch.equal(oa, ob)
+    assert ga.keys() == gb.keys()
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k

@@ -138,7 +138,7 @@ class KPFCNN(nn.Module):
 
     def _fused_upsample_unary(self, x, skip, up_block, unary, batch, drop=None):
         if fused.upunary_eligible(x, skip, unary):
-            return fused.upunary(x, skip, unary, batch.upsamples[up_block.layer_ind - 1], drop)   # one C call each way
+            return fused.upunary(x, skip, unary, batch.upsamples[up_block.layer_ind - 1], drop, batch)   # one C call each way
         assert drop is None
         c_up = x.shape[1]
         w = unary.mlp.weight
@@ -154,6 +154,7 @@ class KPFCNN(nn.Module):
         x = batch.features.clone().detach()
         skips = []
         slots = []
+        link = None
         for block_i, block_op in enumerate(self.encoder_blocks):
             slot = None
             if block_i in self.encoder_skips:
@@ -161,8 +162,12 @@ class KPFCNN(nn.Module):
                 slot = fused.SkipSlot()      # (armed by the strided block call if it is one: fused.resnetb_block)
                 slots.append(slot)
             batch.skip_slot = slot
+            # gate links (fused.GateLink): consecutive block calls hand the activation backward to the consumer's store
+            batch.gate_link_in, batch.gate_link_out = link, fused.GateLink()
+            link = batch.gate_link_out
             x = block_op(x, batch)
             batch.skip_slot = None
+            batch.gate_link_in = batch.gate_link_out = None
             if block_i == 0 and self.feature_dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape[1] % 32 == 0:
                 x = x.to(torch.bfloat16)     # the 3-channel input layer ran in f32; bf16 rows from here on
         nd = len(self.decoder_blocks)
@@ -180,11 +185,15 @@ class KPFCNN(nn.Module):
                     # the same keep decisions as ops.dropout (same seed draw), no pass of its own in either direction
                     drop = (float(self.dropout), int(torch.randint(0, 1 << 62, (1,)).item()))
                     dropped = True
+                batch.gate_link_in, batch.gate_link_out = link, fused.GateLink()
+                link = batch.gate_link_out
                 x = self._fused_upsample_unary(x, fused.skip_tap(skips.pop(), slots.pop()), block_op, nxt, batch, drop)
+                batch.gate_link_in = batch.gate_link_out = None
                 block_i += 2
                 continue
             if block_i in self.decoder_concats:
                 x = torch.cat([x, fused.skip_tap(skips.pop(), slots.pop())], dim=1)
+            link = None                          # (an operator-path step: no link across it)
             x = block_op(x, batch)
             block_i += 1
         if self.dropout and not dropped:

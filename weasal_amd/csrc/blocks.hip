@@ -276,8 +276,14 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     bool added = false;                     // dfeat_add already summed in (by the pool backward's store)
     const float* gin = d->dout;             // gradient entering the convolution's activation
     const float* yconv = d->out;
+    WS_REQUIRE(!(d->gate_dfeat && d->dfeat_add && !(d->strided && want_sc)),
+               "gate_dfeat with dfeat_add needs the strided shortcut (the sum has to be complete before the gate)");
     if (d->w2) {
-        // dz = dout * lrelu'(out), db2 = column sums
+        // dz = dout * lrelu'(out), db2 = column sums (dout_pregated: the consumer has done the multiplication)
+        if (d->dout_pregated) {
+            if (d->db2) WS_TRY(ws_act_bwd_colsum(d->dout, nq, d->out_dim, d->out_dim, nullptr, 0, 0.0f, nullptr, 0, d->db2, tmp, st));
+            dz = const_cast<float*>(d->dout);          // (read only from here on)
+        } else
         WS_TRY(ws_act_bwd_colsum(d->dout, nq, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, dz, d->out_dim, d->db2, tmp, st));
         WS_TRY(fork(0));
         WS_TRY(ws_gemm_xty(dz, nq, d->out_dim, d->out_dim, d->x2, d->conv_out, d->conv_out, d->dw2, tmp_w, stw));
@@ -300,8 +306,16 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
                                                    d->t_pairs, ns, dfsc, ws_block_pool_order ? d->order_s : nullptr, d->dfeat_add, st));
                     added = d->dfeat_add != nullptr;
                 }
-                else
+                else {
                     WS_TRY(ws_max_pool_bwd(dsc, d->arg, nq, d->h, d->in_dim, d->t_offsets, d->t_pairs, ns, dfsc, st));
+                    if (d->dfeat_add) {
+                        WS_REQUIRE(d->in_dim % 4 == 0, "dfeat_add needs in_dim %% 4 == 0");
+                        const int64_t n4 = ns * d->in_dim / 4;
+                        add_rows_kernel<<<ws_grid(n4, 256), 256, 0, st>>>(dfsc, d->dfeat_add, n4);
+                        WS_LAUNCH_CHECK();
+                        added = true;
+                    }
+                }
                 sc_res = dfsc;
             } else {
                 sc_res = dsc;
@@ -317,7 +331,10 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         yconv = d->x2;
     }
     // dz2 = g * lrelu'(x2), dbk
-    if (!gated2)
+    if (!d->w2 && d->dout_pregated) {          // simple block whose consumer has applied the LeakyReLU' already
+        if (d->dbk) WS_TRY(ws_act_bwd_colsum(gin, nq, d->conv_out, d->conv_out, nullptr, 0, 0.0f, nullptr, 0, d->dbk, tmp, st));
+        g2 = const_cast<float*>(gin);              // (read only from here on)
+    } else if (!gated2)
         WS_TRY(ws_act_bwd_colsum(gin, nq, d->conv_out, d->conv_out, yconv, d->conv_out, d->slope, g2, d->conv_out, d->dbk, tmp, st));
     WS_TRY(fork(1));
     WS_TRY(ws_gemm_xty(d->wf, nq, kc, kc, g2, d->conv_out, d->conv_out, d->dwk, tmp_w, stw));
@@ -333,6 +350,7 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
     float* dx1_out = d->w1 ? dx1 : d->dfeat;
     // unary1's LeakyReLU backward rides on the store of K4 / K4G when no bias gradient has to be summed from dz1
     const float* gate1 = (d->w1 && !d->db1 && ws_block_gates) ? d->x1 : nullptr;
+    if (!d->w1 && d->gate_dfeat && d->dfeat) gate1 = d->feat;   // no unary1: K4 / K4G writes dfeat itself -- times LeakyReLU'(feat)
     if (d->grid_blob) {
         WS_REQUIRE(d->key_last && d->grid_overflow && nq == ns, "grid backward needs key_last / overflow and a self-query layer");
         WS_TRY(ws_kpconv_gather_bwd_x_grid_gated(d->s_pts, ns, d->grid_blob, d->grid_nb, d->grid_cells, d->key_last, d->grid_radius, dwf,
@@ -351,9 +369,11 @@ int kpblock_bwd(const ws_kpblock* d, Arena& ar, hipStream_t st, bool run)
         WS_TRY(fork(2));
         WS_TRY(ws_gemm_xty(dx1, ns, d->conv_in, d->conv_in, d->feat, d->in_dim, d->in_dim, d->dw1, tmp_w, stw));
         if (d->dfeat)
-            WS_TRY(ws_gemm_xb_epilogue_strided(dx1, ns, d->conv_in, d->conv_in, d->w1, d->in_dim, 1, d->in_dim, nullptr, sc_res, d->in_dim,
-                                               0, 0.0f, d->dfeat, d->in_dim, tmp, tmp_bytes, st));
+            WS_TRY(ws_gemm_xb_gated_strided(dx1, ns, d->conv_in, d->conv_in, d->w1, d->in_dim, 1, d->in_dim, nullptr, sc_res, d->in_dim,
+                                            0, 0.0f, d->gate_dfeat ? d->feat : nullptr, d->in_dim, d->slope, nullptr, 0, 0.0f, d->dfeat,
+                                            d->in_dim, tmp, tmp_bytes, st));
     } else if (d->dfeat && sc_res) {
+        WS_REQUIRE(!d->gate_dfeat, "gate_dfeat: a block without unary1 has no shortcut to add after the gate");
         const int64_t n4 = ns * d->in_dim / 4;
         add_rows_kernel<<<ws_grid(n4, 256), 256, 0, st>>>(d->dfeat, sc_res, n4);
         WS_LAUNCH_CHECK();
@@ -378,6 +398,7 @@ int check_upunary(const ws_upunary* d)
                        d->out_dim);
     WS_REQUIRE(d->drop_p >= 0.0f && d->drop_p < 1.0f, "bad drop probability %g", (double)d->drop_p);
     if (d->drop_p > 0.0f && !d->relu) return ws_fail(WS_ERR_UNSUPPORTED, "decoder step: the fused dropout follows a LeakyReLU (relu = 0)");
+    WS_REQUIRE(!(d->dout_pregated && (d->drop_p > 0.0f || !d->relu)), "dout_pregated needs this step's LeakyReLU and no fused dropout");
     return WS_OK;
 }
 
@@ -430,6 +451,8 @@ int upunary_bwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
         WS_TRY(ws_act_bwd_colsum_dropout(d->dout, d->nf, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, d->drop_p, d->drop_seed, dz,
                                          d->out_dim, d->db, tmp, st));
         g = dz;
+    } else if (d->relu && d->dout_pregated) {      // the consumer has applied this step's LeakyReLU' already
+        if (d->db) WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, nullptr, 0, 0.0f, nullptr, 0, d->db, tmp, st));
     } else if (d->relu) {
         WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, dz, d->out_dim, d->db, tmp, st));
         g = dz;
@@ -447,8 +470,8 @@ int upunary_bwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
     WS_TRY(ws_gemm_xty(dyc, d->nc, d->out_dim, d->out_dim, d->xc, d->c_up, d->c_up, dwt, tmp, st));
     WS_HIP(hipMemcpy2DAsync(d->dw, sizeof(float) * cw, dwt, sizeof(float) * d->c_up, sizeof(float) * d->c_up, d->out_dim,
                             hipMemcpyDeviceToDevice, st));
-    return ws_gemm_xb_epilogue_strided(dyc, d->nc, d->out_dim, d->out_dim, d->w, d->ldw, 1, d->c_up, nullptr, nullptr, 0, 0, 0.0f, d->dxc,
-                                       d->c_up, tmp, tmp_bytes, st);
+    return ws_gemm_xb_gated_strided(dyc, d->nc, d->out_dim, d->out_dim, d->w, d->ldw, 1, d->c_up, nullptr, nullptr, 0, 0, 0.0f,
+                                    d->gate_dxc ? d->xc : nullptr, d->c_up, d->slope, nullptr, 0, 0.0f, d->dxc, d->c_up, tmp, tmp_bytes, st);
 }
 
 }  // namespace

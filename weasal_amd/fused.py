@@ -49,7 +49,8 @@ class KPBlockDesc(C.Structure):
                 ("w1", _vp), ("b1", _vp), ("wk", _vp), ("bk", _vp), ("w2", _vp), ("b2", _vp), ("ws", _vp), ("bs", _vp),
                 ("feat", _vp), ("x1", _vp), ("wf", _vp), ("x2", _vp), ("pooled", _vp), ("arg", _vp), ("out", _vp),
                 ("dout", _vp), ("dfeat", _vp), ("dw1", _vp), ("db1", _vp), ("dwk", _vp), ("dbk", _vp), ("dw2", _vp),
-                ("db2", _vp), ("dws", _vp), ("timed", _i32), ("rows_sorted", _i32), ("infer", _i32), ("dfeat_add", _vp)]
+                ("db2", _vp), ("dws", _vp), ("timed", _i32), ("rows_sorted", _i32), ("infer", _i32), ("dout_pregated", _i32),
+                ("gate_dfeat", _i32), ("dfeat_add", _vp)]
 
 
 class UpUnaryDesc(C.Structure):
@@ -58,7 +59,7 @@ class UpUnaryDesc(C.Structure):
                 ("ups", _vp), ("h_up", _i32), ("t_offsets", _vp), ("t_pairs", _vp),
                 ("w", _vp), ("ldw", _i64), ("b", _vp), ("out_dim", _i32), ("relu", _i32), ("slope", _f32),
                 ("yc", _vp), ("out", _vp), ("dout", _vp), ("dxc", _vp), ("dskip", _vp), ("dw", _vp), ("db", _vp),
-                ("drop_p", _f32), ("drop_seed", C.c_uint64)]
+                ("drop_p", _f32), ("drop_seed", C.c_uint64), ("dout_pregated", _i32), ("gate_dxc", _i32)]
 
 
 _GATES_SET = False
@@ -109,7 +110,7 @@ def _scratch(nbytes, device):
 class _Geom:
     """geometry + widths of one block call (plain Python object carried through the autograd node)"""
     __slots__ = ("q_pts", "s_pts", "inds", "kp", "extent", "order_q", "order_s", "grid", "table", "in_dim", "conv_in",
-                 "conv_out", "out_dim", "strided", "slope", "has", "rows_sorted", "infer", "skip_slot")
+                 "conv_out", "out_dim", "strided", "slope", "has", "rows_sorted", "infer", "skip_slot", "link_in", "link_out")
 
     def fill(self, d):
         d.q_pts, d.nq = self.q_pts.data_ptr(), self.q_pts.shape[0]
@@ -144,6 +145,40 @@ class SkipSlot:
 
     def __init__(self):
         self.grad, self.armed, self.taken = None, False, False
+
+
+class GateLink:
+    """Producer -> consumer link between two consecutive block calls.  The consumer's input IS the producer's LeakyReLU output
+    and nothing else reads it (but a skip connection whose share arrives through a SkipSlot), so the consumer's backward can
+    multiply the gradient it writes by LeakyReLU'(input) on the store (ws_kpblock.gate_dfeat / ws_upunary.gate_dxc) and the
+    producer's backward skip its first pass over [rows, channels] (dout_pregated) -- blocks.py:473-507's activation backward
+    without a pass of its own.  The consumer decides in EVERY backward (pregated is rewritten each time) and only when every
+    contribution to the gradient is in its hands."""
+    __slots__ = ("out", "pregated")
+
+    def __init__(self):
+        self.out, self.pregated = None, False
+
+
+GATE_LINKS = os.environ.get("WEASAL_GATE_LINKS", "1") != "0"       # A/B switch: 0 = every block runs its own activation backward
+
+
+def _link_in(batch, x):
+    """the incoming link of the block about to run, if its producer ran as a block call and x is that call's output itself"""
+    link = getattr(batch, "gate_link_in", None)
+    if (link is None or not GATE_LINKS or link.out is None or link.out is not x or not torch.is_grad_enabled()
+            or not x.requires_grad or x.dtype != torch.float32):
+        return None
+    return link
+
+
+def _link_out(batch, out, relu=True):
+    """hand the block's output to the link its consumer will look at"""
+    link = getattr(batch, "gate_link_out", None)
+    if link is not None and GATE_LINKS and relu and torch.is_grad_enabled() and out.requires_grad:
+        link.out = out
+        return link
+    return None
 
 
 class _SkipTap(torch.autograd.Function):
@@ -245,6 +280,16 @@ class _KPBlockFn(torch.autograd.Function):
                 global skip_slot_hits
                 skip_slot_hits += 1
         d.dfeat_add = _p(extra)
+        # gate links: this block's output gradient may arrive with the LeakyReLU' applied; its input gradient may leave so
+        lo, li = getattr(g, "link_out", None), getattr(g, "link_in", None)
+        d.dout_pregated = 1 if (lo is not None and lo.pregated) else 0
+        if li is not None:
+            # (an armed slot whose share has not arrived will be added by autograd afterwards: no gate then)
+            complete = slot is None or not slot.armed or extra is not None
+            li.pregated = bool(dfeat is not None and complete and (extra is None or (g.strided and w2 is not None)))
+            d.gate_dfeat = 1 if li.pregated else 0
+            global gate_link_hits
+            gate_link_hits += d.gate_dfeat
         # parameter gradients: one tensor each (autograd adopts an unshared, contiguous gradient as .grad without a copy)
         grads = [None if p is None else torch.empty_like(p) for p in (w1, b1, wk, bk, w2, b2, wsc)]
         d.dw1, d.db1, d.dwk, d.dbk, d.dw2, d.db2, d.dws = [_p(t) for t in grads]
@@ -258,6 +303,7 @@ class _KPBlockFn(torch.autograd.Function):
         return dfeat, dw1, db1, dwk, dbk, dw2, db2, dws, dbs, None
 
 
+gate_link_hits = 0      # (tests) input gradients written with the producer's LeakyReLU' so far
 skip_slot_hits = 0      # (tests) skip gradients summed inside a strided block's backward so far
 SKIP_SLOTS = os.environ.get("WEASAL_SKIP_SLOTS", "1") != "0"      # A/B switch: 0 = autograd adds the two gradients of a skip tensor
 
@@ -284,6 +330,7 @@ def _geometry(conv, q_pts, s_pts, inds, strided):
     g.grid = grid if (grid is not None and grid.ns == ns and grid.max_count <= ops.GRID_NARROW_MAX) else None
     g.table = None
     g.skip_slot = None
+    g.link_in = g.link_out = None
     g.strided = strided
     g.rows_sorted = ops.rows_cutoff_pays(g.inds, conv.radius)      # searched with the deformable radius: stop at the kernel's reach
     g.infer = not torch.is_grad_enabled()      # a forward pass nobody will differentiate (the testers' loops run under no_grad)
@@ -316,7 +363,11 @@ def simple_block(block, x, batch, q_pts, s_pts, inds):
     g.slope = 0.1
     if torch.is_grad_enabled() and x.requires_grad and g.grid is None:
         g.table = ops.transposed_table(g.inds, g.s_pts.shape[0])
-    return _KPBlockFn.apply(x, None, None, conv.weights, block.batch_norm.epilogue_bias(), None, None, None, None, g)
+    if getattr(batch, "skip_slot", None) is None:      # (a skip tensor has a second reader this block knows nothing about)
+        g.link_in = _link_in(batch, x)
+    out = _KPBlockFn.apply(x, None, None, conv.weights, block.batch_norm.epilogue_bias(), None, None, None, None, g)
+    g.link_out = _link_out(batch, out)
+    return out
 
 
 def resnetb_block(block, x, batch, q_pts, s_pts, inds):
@@ -334,19 +385,24 @@ def resnetb_block(block, x, batch, q_pts, s_pts, inds):
         g.table = ops.transposed_table(g.inds, g.s_pts.shape[0])
     u1 = block.unary1 if isinstance(block.unary1, torch.nn.Module) and hasattr(block.unary1, "mlp") else None
     us = block.unary_shortcut if hasattr(block.unary_shortcut, "mlp") else None
-    return _KPBlockFn.apply(x,
-                            u1.mlp.weight if u1 is not None else None, u1.batch_norm.epilogue_bias() if u1 is not None else None,
-                            conv.weights, block.batch_norm_conv.epilogue_bias(),
-                            block.unary2.mlp.weight, block.unary2.batch_norm.epilogue_bias(),
-                            us.mlp.weight if us is not None else None, us.batch_norm.epilogue_bias() if us is not None else None,
-                            g)
+    if getattr(batch, "skip_slot", None) is None or g.skip_slot is not None:
+        # (a skip tensor has a second reader: only with its slot armed does this block get to see that share)
+        g.link_in = _link_in(batch, x)
+    out = _KPBlockFn.apply(x,
+                           u1.mlp.weight if u1 is not None else None, u1.batch_norm.epilogue_bias() if u1 is not None else None,
+                           conv.weights, block.batch_norm_conv.epilogue_bias(),
+                           block.unary2.mlp.weight, block.unary2.batch_norm.epilogue_bias(),
+                           us.mlp.weight if us is not None else None, us.batch_norm.epilogue_bias() if us is not None else None,
+                           g)
+    g.link_out = _link_out(batch, out)
+    return out
 
 
 class _UpUnaryFn(torch.autograd.Function):
     """nearest_upsample -> concat(skip) -> unary as up(x @ Wx^T) + skip @ Ws^T (architectures.py:339-343)"""
 
     @staticmethod
-    def forward(ctx, xc, skip, w, b, ups, table, relu, drop_p=0.0, drop_seed=0):
+    def forward(ctx, xc, skip, w, b, ups, table, relu, drop_p=0.0, drop_seed=0, links=None):
         lib = _bind()
         dev = xc.device
         xc, skip, w = xc.contiguous(), skip.contiguous(), w.contiguous()
@@ -367,6 +423,7 @@ class _UpUnaryFn(torch.autograd.Function):
         scratch = _scratch(nbytes, dev)
         check(lib.ws_upunary_fwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
         ctx.table, ctx.relu, ctx.drop = table, relu, (float(drop_p), int(drop_seed))
+        ctx.links = links if links is not None else [None, None]          # [incoming (xc's producer), outgoing]
         ctx.save_for_backward(xc, skip, w, b, ups, out)
         return out
 
@@ -386,6 +443,13 @@ class _UpUnaryFn(torch.autograd.Function):
         d.w, d.ldw, d.b, d.out_dim, d.relu, d.slope = w.data_ptr(), w.stride(0), _p(b), out_dim, 1 if ctx.relu else 0, 0.1
         d.out, d.dout = out.data_ptr(), dout.data_ptr()
         d.drop_p, d.drop_seed = ctx.drop
+        li, lo = ctx.links
+        d.dout_pregated = 1 if (lo is not None and lo.pregated) else 0
+        if li is not None:
+            li.pregated = bool(ctx.needs_input_grad[0])
+            d.gate_dxc = 1 if li.pregated else 0
+            global gate_link_hits
+            gate_link_hits += d.gate_dxc
         dxc, dskip = torch.empty_like(xc), torch.empty_like(skip)
         dw = torch.empty_like(w)
         db = torch.empty_like(b) if b is not None else None
@@ -395,7 +459,7 @@ class _UpUnaryFn(torch.autograd.Function):
             check(1)
         scratch = _scratch(nbytes, dev)
         check(lib.ws_upunary_bwd(C.byref(d), scratch.data_ptr(), scratch.numel(), current_stream()))
-        return dxc, dskip, dw, db, None, None, None, None, None
+        return dxc, dskip, dw, db, None, None, None, None, None, None
 
 
 def upunary_eligible(x, skip, unary):
@@ -404,14 +468,19 @@ def upunary_eligible(x, skip, unary):
             and unary.out_dim % 32 == 0 and x.shape[0] > 0 and skip.shape[0] >= MIN_ROWS)
 
 
-def upunary(x, skip, unary, ups, drop=None):
+def upunary(x, skip, unary, ups, drop=None, batch=None):
     """drop = (p, seed): nn.Dropout(p) applied to the step's output inside its last epilogue (the bits of ops.dropout with that
     seed); needs the unary's LeakyReLU"""
     ups = ups.contiguous()
     ups = ups if ups.dtype == torch.int64 else ups.to(torch.int64)
     table = ops.col0_table(ups, x.shape[0]) if torch.is_grad_enabled() else None      # (only the backward reads it)
+    links = [_link_in(batch, x) if batch is not None else None, None]
     if drop is not None:
         if unary.no_relu:
             raise _lib.WeasalHipError("upunary: the fused dropout follows the unary's LeakyReLU")
-        return _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, True, float(drop[0]), int(drop[1]))
-    return _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, not unary.no_relu)
+        return _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, True, float(drop[0]), int(drop[1]),
+                                links)
+    out = _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, not unary.no_relu, 0.0, 0, links)
+    if batch is not None:
+        links[1] = _link_out(batch, out, relu=not unary.no_relu)
+    return out
