@@ -568,7 +568,8 @@ typedef struct ws_upunary {
      * forward's last epilogue write dropout(out) (keep decision = function of (drop_seed, element index), the bits of
      * ws_dropout_apply) and the backward treat `dout` as the gradient of that dropped tensor.  Needs relu != 0. */
     float drop_p; uint64_t drop_seed;
-    int32_t dout_pregated;               /* as in ws_kpblock: dout already multiplied by LeakyReLU'(out) by the consumer */
+    int32_t dout_pregated;               /* as in ws_kpblock: dout already multiplied by LeakyReLU'(out) by the consumer (and run
+                                            through the dropout backward when drop_p > 0: ws_gemm_xb_gate_dropout) */
     int32_t gate_dxc;                    /* backward: write dxc * LeakyReLU'(xc) (xc = the activated output of its producer) */
 } ws_upunary;
 
@@ -592,6 +593,14 @@ int ws_gemm_xb_dropout_strided(const float* x, int64_t m, int32_t k, int64_t ldx
                                int64_t b_col_stride, int32_t n, const float* bias, const float* residual, int64_t ldr,
                                int32_t act, float slope, float drop_p, uint64_t drop_seed, float* y, int64_t ldy, void* scratch,
                                int64_t scratch_bytes, void* stream);
+
+/* dX = dZ @ B (B row-major [K, N]) as the gradient of a layer INPUT that came out of a LeakyReLU and, optionally, an nn.Dropout
+ * after it: y = dropout_bwd(x @ b) * LeakyReLU'(gate_y), in that order (the order of the separate backward passes: same bits);
+ * gate_y [m, n] = the activated (and dropped: same signs where kept) tensor, NULL = no gate; drop_p = 0 = no dropout.  The
+ * producer of gate_y then needs no activation-backward pass of its own (ws_kpblock / ws_upunary: dout_pregated). */
+int ws_gemm_xb_gate_dropout(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n, const float* gate_y,
+                            int64_t ldg, float gate_slope, float drop_p, uint64_t drop_seed, float* y, int64_t ldy, void* scratch,
+                            int64_t scratch_bytes, void* stream);
 
 /* ws_act_bwd_colsum for a tensor that went through that dropout: dy is the gradient of dropout(y') where y' is the activated
  * output and y = dropout(y') is what was kept (same sign wherever the mask keeps): dz = dropout_bwd(dy) * act'(y), column sums. */

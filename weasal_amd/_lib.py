@@ -51,6 +51,7 @@ SIGNATURES = {
     "ws_dropout_apply": (C.c_int, [_vp, _i64, C.c_float, C.c_uint64, _vp, _vp]),
     "ws_gemm_xb_dropout_strided": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _f32, _f32, C.c_uint64,
                                              _vp, _i64, _vp, _i64, _vp]),
+    "ws_gemm_xb_gate_dropout": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i64, _f32, _f32, C.c_uint64, _vp, _i64, _vp, _i64, _vp]),
     "ws_act_bwd_colsum_dropout": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _f32, _f32, C.c_uint64, _vp, _i64, _vp, _vp, _vp]),
     "ws_pyramid_build": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ws_pyramid_desc_bytes": (_i64, []),

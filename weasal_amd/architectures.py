@@ -197,12 +197,20 @@ class KPFCNN(nn.Module):
             x = block_op(x, batch)
             block_i += 1
         if self.dropout and not dropped:
+            link = None                      # (a dropout pass of its own sits between the decoder and the head)
             if DROPOUT_KERNEL and self.training and x.is_cuda and x.dtype == torch.float32 and x.requires_grad:
                 x = ops.dropout(x, float(self.dropout))          # one pass each way, mask recomputed instead of stored
             else:
                 x = self.droplayer(x)
+        # the head's two unary blocks continue the chain of gate links (fused.GateLink): head_softmax's dX product applies
+        # head_mlp's LeakyReLU', head_mlp's the last decoder step's (and its fused dropout)
+        batch.gate_link_in, batch.gate_link_out = link, fused.GateLink()
+        link = batch.gate_link_out
         x = self.head_mlp(x, batch)
-        return self.head_softmax(x, batch)
+        batch.gate_link_in, batch.gate_link_out = link, None
+        x = self.head_softmax(x, batch)
+        batch.gate_link_in = None
+        return x
 
     def _label_lut(self, device):
         """label value -> class position table [vmax + 2] (architectures.py:362-365); the last, spare entry is the -1

@@ -72,6 +72,8 @@ def global_average(x, batch_lengths):
 # ---------------------------------------------------------------------------------------------
 # KPConv (blocks.py:144-379)
 # ---------------------------------------------------------------------------------------------
+_MATMUL_EPILOGUE = ops.matmul_epilogue      # (oracle.kpconv_ref.cpu_reference_mode swaps ops.*: no links then)
+
 class KPConv(nn.Module):
 
     def __init__(self, kernel_size, p_dim, in_channels, out_channels, KP_extent, radius,
@@ -259,9 +261,9 @@ class UnaryBlock(nn.Module):
         self.out_f32 = False     # bf16 feature rows only: keep this block's output in f32 (the logits)
 
     def forward(self, x, batch=None):
-        return self.forward_fused(x)
+        return self.forward_fused(x, batch=batch)
 
-    def forward_fused(self, x, residual=None, slope_override=None):
+    def forward_fused(self, x, residual=None, slope_override=None, batch=None):
         """mlp -> batch_norm(identity | + bias) [-> + residual] -> LeakyReLU, in one GEMM.
         slope_override: activation applied although the block itself has no_relu (the residual sum of
         ResnetBottleneckBlock, blocks.py:709)."""
@@ -269,8 +271,19 @@ class UnaryBlock(nn.Module):
         if x.dtype == torch.bfloat16:
             return ops.matmul_epilogue(x, self.mlp.weight.t(), bias=self.batch_norm.epilogue_bias(), residual=residual,
                                        slope=slope, out_f32=self.out_f32)
-        return ops.matmul_epilogue(x, self.mlp.weight.t(), bias=self.batch_norm.epilogue_bias(), residual=residual,
-                                   slope=slope)
+        # gate links (fused.GateLink) when the caller has set them up on the batch (KPFCNN's head): float32 kernel path only
+        links = None
+        linked = batch is not None and residual is None and (getattr(batch, "gate_link_in", None) is not None
+                                                             or getattr(batch, "gate_link_out", None) is not None)
+        if linked and ops.matmul_epilogue is _MATMUL_EPILOGUE and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and ops.FUSED_EPILOGUE and x.shape[0] >= ops.GEMM_MIN_ROWS:
+            from . import fused
+            links = fused.linear_links(batch, x, True)
+        if links is None:
+            return ops.matmul_epilogue(x, self.mlp.weight.t(), bias=self.batch_norm.epilogue_bias(), residual=residual, slope=slope)
+        out = ops.matmul_epilogue(x, self.mlp.weight.t(), bias=self.batch_norm.epilogue_bias(), residual=residual,
+                                  slope=slope, links=links)
+        fused.linear_links_done(batch, links, out, slope is not None)
+        return out
 
     def __repr__(self):
         return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(

@@ -398,7 +398,7 @@ int check_upunary(const ws_upunary* d)
                        d->out_dim);
     WS_REQUIRE(d->drop_p >= 0.0f && d->drop_p < 1.0f, "bad drop probability %g", (double)d->drop_p);
     if (d->drop_p > 0.0f && !d->relu) return ws_fail(WS_ERR_UNSUPPORTED, "decoder step: the fused dropout follows a LeakyReLU (relu = 0)");
-    WS_REQUIRE(!(d->dout_pregated && (d->drop_p > 0.0f || !d->relu)), "dout_pregated needs this step's LeakyReLU and no fused dropout");
+    WS_REQUIRE(!(d->dout_pregated && !d->relu), "dout_pregated needs this step's LeakyReLU");
     return WS_OK;
 }
 
@@ -447,12 +447,12 @@ int upunary_bwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
     }
     // dz = dout * lrelu'(out) (identity when !relu), db
     const float* g = d->dout;
-    if (d->drop_p > 0.0f) {
+    if (d->relu && d->dout_pregated) {             // the consumer has applied this step's LeakyReLU' (and dropout backward) already
+        if (d->db) WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, nullptr, 0, 0.0f, nullptr, 0, d->db, tmp, st));
+    } else if (d->drop_p > 0.0f) {
         WS_TRY(ws_act_bwd_colsum_dropout(d->dout, d->nf, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, d->drop_p, d->drop_seed, dz,
                                          d->out_dim, d->db, tmp, st));
         g = dz;
-    } else if (d->relu && d->dout_pregated) {      // the consumer has applied this step's LeakyReLU' already
-        if (d->db) WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, nullptr, 0, 0.0f, nullptr, 0, d->db, tmp, st));
     } else if (d->relu) {
         WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, d->out, d->out_dim, d->slope, dz, d->out_dim, d->db, tmp, st));
         g = dz;

@@ -49,8 +49,15 @@ __device__ __forceinline__ const float* xb_res_row(const float* residual, int64_
     const int64_t i = g.rrows[row * g.rld];
     return (i >= 0 && i < g.rn) ? residual + i * ldr : nullptr;
 }
+// order: dropout, then the LeakyReLU' gate, then the byte mask -- as a backward, dropout_bwd then activation_bwd is the order the
+// separate passes run in (d u = dropout_bwd(d x_d); dz = d u * lrelu'(u)); as a forward only one of them is set
 __device__ __forceinline__ void xb_gate4(float4& v, const XbGate& g, int64_t row, int col)
 {
+    if (g.drop.on) {
+        const unsigned long long i = (unsigned long long)(row * g.dn + col);
+        v.x = ws_drop1(v.x, g.drop, i); v.y = ws_drop1(v.y, g.drop, i + 1);
+        v.z = ws_drop1(v.z, g.drop, i + 2); v.w = ws_drop1(v.w, g.drop, i + 3);
+    }
     if (g.y) {
         const float4 q = *reinterpret_cast<const float4*>(g.y + row * g.ld + col);
         v.x *= q.x > 0.0f ? 1.0f : g.slope; v.y *= q.y > 0.0f ? 1.0f : g.slope;
@@ -61,17 +68,12 @@ __device__ __forceinline__ void xb_gate4(float4& v, const XbGate& g, int64_t row
         v.x = (mk & 0xffu) ? v.x * g.mscale : 0.0f;       v.y = (mk & 0xff00u) ? v.y * g.mscale : 0.0f;
         v.z = (mk & 0xff0000u) ? v.z * g.mscale : 0.0f;   v.w = (mk & 0xff000000u) ? v.w * g.mscale : 0.0f;
     }
-    if (g.drop.on) {
-        const unsigned long long i = (unsigned long long)(row * g.dn + col);
-        v.x = ws_drop1(v.x, g.drop, i); v.y = ws_drop1(v.y, g.drop, i + 1);
-        v.z = ws_drop1(v.z, g.drop, i + 2); v.w = ws_drop1(v.w, g.drop, i + 3);
-    }
 }
 __device__ __forceinline__ float xb_gate1(float v, const XbGate& g, int64_t row, int col)
 {
+    if (g.drop.on) v = ws_drop1(v, g.drop, (unsigned long long)(row * g.dn + col));
     if (g.y) v *= g.y[row * g.ld + col] > 0.0f ? 1.0f : g.slope;
     if (g.mask) v = g.mask[row * g.ldm + col] ? v * g.mscale : 0.0f;
-    if (g.drop.on) v = ws_drop1(v, g.drop, (unsigned long long)(row * g.dn + col));
     return v;
 }
 
@@ -1445,6 +1447,19 @@ int ws_gemm_xb_dropout_strided(const float* x, int64_t m, int32_t k, int64_t ldx
     gate.dn = n;
     return gemm_xb_impl(x, m, k, ldx, b, n, bias, residual, ldr, act, slope, y, ldy, scratch, scratch_bytes, stream,
                         b_row_stride, b_col_stride, gate);
+}
+
+int ws_gemm_xb_gate_dropout(const float* x, int64_t m, int32_t k, int64_t ldx, const float* b, int32_t n, const float* gate_y,
+                            int64_t ldg, float gate_slope, float drop_p, uint64_t drop_seed, float* y, int64_t ldy, void* scratch,
+                            int64_t scratch_bytes, void* stream)
+{
+    WS_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "bad drop probability %g", (double)drop_p);
+    WS_REQUIRE(!gate_y || ldg >= n, "gate leading dimension too small");
+    XbGate gate{};
+    gate.y = gate_y; gate.ld = ldg; gate.slope = gate_slope;
+    gate.drop = ws_drop_args(drop_p, drop_seed);
+    gate.dn = n;
+    return gemm_xb_impl(x, m, k, ldx, b, n, nullptr, nullptr, 0, 0, 0.0f, y, ldy, scratch, scratch_bytes, stream, -1, 1, gate);
 }
 
 // private to the library (ws_common.h): the strided product with the whole epilogue menu -- dropout (drop_p > 0) and / or a

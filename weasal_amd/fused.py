@@ -154,13 +154,28 @@ class GateLink:
     producer's backward skip its first pass over [rows, channels] (dout_pregated) -- blocks.py:473-507's activation backward
     without a pass of its own.  The consumer decides in EVERY backward (pregated is rewritten each time) and only when every
     contribution to the gradient is in its hands."""
-    __slots__ = ("out", "pregated")
+    __slots__ = ("out", "pregated", "drop", "slope")
 
     def __init__(self):
         self.out, self.pregated = None, False
+        self.drop = None            # (p, seed) when the producer's output went through its fused dropout: the gate undoes it too
+        self.slope = 0.1            # the producer's LeakyReLU slope
 
 
 GATE_LINKS = os.environ.get("WEASAL_GATE_LINKS", "1") != "0"       # A/B switch: 0 = every block runs its own activation backward
+
+
+def linear_links(batch, x, eligible):
+    """[incoming, outgoing] links of a UnaryBlock called between block calls (the head); the outgoing one is completed by
+    linear_links_done once the output exists"""
+    if not eligible or batch is None or not GATE_LINKS:
+        return None
+    return [_link_in(batch, x), None]
+
+
+def linear_links_done(batch, links, out, relu):
+    if links is not None and batch is not None:
+        links[1] = _link_out(batch, out, relu=relu)
 
 
 def _link_in(batch, x):
@@ -478,8 +493,13 @@ def upunary(x, skip, unary, ups, drop=None, batch=None):
     if drop is not None:
         if unary.no_relu:
             raise _lib.WeasalHipError("upunary: the fused dropout follows the unary's LeakyReLU")
-        return _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, True, float(drop[0]), int(drop[1]),
-                                links)
+        out = _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, True, float(drop[0]), int(drop[1]),
+                               links)
+        if batch is not None:
+            links[1] = _link_out(batch, out)
+            if links[1] is not None:
+                links[1].drop = (float(drop[0]), int(drop[1]))
+        return out
     out = _UpUnaryFn.apply(x, skip, unary.mlp.weight, unary.batch_norm.epilogue_bias(), ups, table, not unary.no_relu, 0.0, 0, links)
     if batch is not None:
         links[1] = _link_out(batch, out, relu=not unary.no_relu)

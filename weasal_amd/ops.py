@@ -694,8 +694,11 @@ class _MatmulEpilogue(torch.autograd.Function):
     backward uses the output (sign(y) == sign(pre-activation) for slope > 0)."""
 
     @staticmethod
-    def forward(ctx, x, b, bias, residual, slope):
+    def forward(ctx, x, b, bias, residual, slope, links=None):
+        # links = [incoming, outgoing] fused.GateLink or None: see fused.GateLink -- the consumer's dX product applies the
+        # producer's LeakyReLU' (and dropout backward), the producer skips its activation-backward pass
         lib = _lib.lib()
+        ctx.links = links if links is not None else [None, None]
         xc, bc = _rowmajor(x), b.contiguous()
         rc = _rowmajor(residual) if residual is not None else None
         biasc = bias.contiguous() if bias is not None else None
@@ -714,18 +717,38 @@ class _MatmulEpilogue(torch.autograd.Function):
         x, b, y = ctx.saved_tensors
         dy = _rowmajor(dy)
         want_bias = ctx.has[0] and ctx.needs_input_grad[2]
-        dz, dbias = _act_bwd_colsum(dy, y if ctx.slope is not None else None, ctx.slope, want_bias)
+        li, lo = ctx.links
+        if lo is not None and lo.pregated and ctx.slope is not None:
+            dz, dbias = _act_bwd_colsum(dy, None, None, want_bias)            # (the consumer has applied this layer's LeakyReLU')
+        else:
+            dz, dbias = _act_bwd_colsum(dy, y if ctx.slope is not None else None, ctx.slope, want_bias)
         dx = db = dres = None
+        if li is not None:
+            # (only on the rows-on-lanes MFMA kernel, whose epilogue reads the gate rows 16 bytes per lane: through the scalar
+            # epilogue of the shallow-product kernel the 9-logit dX took 247 instead of 96 us with the gate on it)
+            li.pregated = bool(ctx.needs_input_grad[0]) and dz.shape[1] % 32 == 0 and b.shape[0] % 4 == 0
         if ctx.needs_input_grad[0]:
-            dx = _gemm_xb(dz, b.t().contiguous())
+            if li is not None and li.pregated:
+                # dx = dropout_bwd(dz @ b^T) * LeakyReLU'(x): x is the producer's activated (and dropped) output
+                bt = b.t().contiguous()
+                m, k = dz.shape
+                n = bt.shape[1]
+                dx = torch.empty((m, n), dtype=torch.float32, device=dz.device)
+                sb = max(int(lib.ws_gemm_xb_scratch_bytes(m, k, n)), 0)
+                scratch = torch.empty(max(sb, 16), dtype=torch.uint8, device=dz.device)
+                p_drop, seed = li.drop if li.drop is not None else (0.0, 0)
+                check(lib.ws_gemm_xb_gate_dropout(ptr(dz), m, k, dz.stride(0), ptr(bt), n, ptr(x), x.stride(0), float(li.slope),
+                                                  float(p_drop), int(seed), ptr(dx), n, ptr(scratch), sb, current_stream()))
+            else:
+                dx = _gemm_xb(dz, b.t().contiguous())
         if ctx.needs_input_grad[1]:
             db = _gemm_xty(lib, x, dz)
         if ctx.has[1] and ctx.needs_input_grad[3]:
             dres = dz
-        return dx, db, dbias, dres, None
+        return dx, db, dbias, dres, None, None
 
 
-def matmul_epilogue(x, b, bias=None, residual=None, slope=None, out_f32=False):
+def matmul_epilogue(x, b, bias=None, residual=None, slope=None, out_f32=False, links=None):
     """act(x @ b + bias + residual): one MFMA kernel (b is [K,N]; short, deep products of the deep layers split K).
     GEMM_MIN_ROWS > 0 (diagnostics) hands operands with fewer rows to the library GEMM through torch.
     bf16 rows (x.dtype bfloat16) always take the bf16 MFMA kernel; out_f32 keeps its output in f32."""
@@ -733,7 +756,9 @@ def matmul_epilogue(x, b, bias=None, residual=None, slope=None, out_f32=False):
     if x.dtype == torch.bfloat16 and x.dim() == 2:
         return _MatmulEpilogueBF16.apply(x, b, bias, residual, slope, bool(out_f32))
     if FUSED_EPILOGUE and x.dim() == 2 and x.shape[0] >= GEMM_MIN_ROWS and x.dtype == torch.float32:
-        return _MatmulEpilogue.apply(x, b, bias, residual, slope)
+        return _MatmulEpilogue.apply(x, b, bias, residual, slope, links)
+    if links is not None and (links[0] is not None or links[1] is not None):
+        raise _lib.WeasalHipError("matmul_epilogue: gate links need the float32 kernel path")
     if not FUSED_EPILOGUE:
         y = matmul(x, b)
         if bias is not None:
