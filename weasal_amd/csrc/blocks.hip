@@ -430,7 +430,6 @@ int upunary_bwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
 {
     float* dz = ar.take<float>(d->nf * d->out_dim);
     float* dyc = ar.take<float>(d->nc * d->out_dim);
-    float* dwt = ar.take<float>((int64_t)d->out_dim * (d->c_up > d->c_skip ? d->c_up : d->c_skip));
     int64_t tmp_bytes = max3(ws_act_bwd_colsum_scratch_bytes(d->nf, d->out_dim), ws_gemm_xty_scratch_bytes(d->nf, d->out_dim, d->c_skip),
                              ws_gemm_xty_scratch_bytes(d->nc, d->out_dim, d->c_up));
     tmp_bytes = max3(tmp_bytes, ws_gemm_xb_scratch_bytes(d->nf, d->out_dim, d->c_skip), ws_gemm_xb_scratch_bytes(d->nc, d->out_dim, d->c_up));
@@ -460,16 +459,13 @@ int upunary_bwd(const ws_upunary* d, Arena& ar, hipStream_t st, bool run)
         WS_TRY(ws_act_bwd_colsum(d->dout, d->nf, d->out_dim, d->out_dim, nullptr, 0, 0.0f, nullptr, 0, d->db, tmp, st));
     }
     // skip side
-    WS_TRY(ws_gemm_xty(g, d->nf, d->out_dim, d->out_dim, d->skip, d->c_skip, d->c_skip, dwt, tmp, st));
-    WS_HIP(hipMemcpy2DAsync(d->dw + d->c_up, sizeof(float) * cw, dwt, sizeof(float) * d->c_skip, sizeof(float) * d->c_skip, d->out_dim,
-                            hipMemcpyDeviceToDevice, st));
+    // (the two halves of dw [out, c_up + c_skip] are written in place: column blocks of pitch cw)
+    WS_TRY(ws_priv_gemm_xty_pitched(g, d->nf, d->out_dim, d->out_dim, d->skip, d->c_skip, d->c_skip, d->dw + d->c_up, cw, tmp, st));
     WS_TRY(ws_gemm_xb_epilogue_strided(g, d->nf, d->out_dim, d->out_dim, d->w + d->c_up, d->ldw, 1, d->c_skip, nullptr, nullptr, 0, 0, 0.0f,
                                        d->dskip, d->c_skip, tmp, tmp_bytes, st));
     // coarse side: nearest upsampling backward, then the x-part of the unary
     WS_TRY(ws_closest_pool_bwd(g, d->nf, 1, d->out_dim, d->t_offsets, d->t_pairs, d->nc, dyc, st));
-    WS_TRY(ws_gemm_xty(dyc, d->nc, d->out_dim, d->out_dim, d->xc, d->c_up, d->c_up, dwt, tmp, st));
-    WS_HIP(hipMemcpy2DAsync(d->dw, sizeof(float) * cw, dwt, sizeof(float) * d->c_up, sizeof(float) * d->c_up, d->out_dim,
-                            hipMemcpyDeviceToDevice, st));
+    WS_TRY(ws_priv_gemm_xty_pitched(dyc, d->nc, d->out_dim, d->out_dim, d->xc, d->c_up, d->c_up, d->dw, cw, tmp, st));
     return ws_gemm_xb_gated_strided(dyc, d->nc, d->out_dim, d->out_dim, d->w, d->ldw, 1, d->c_up, nullptr, nullptr, 0, 0, 0.0f,
                                     d->gate_dxc ? d->xc : nullptr, d->c_up, d->slope, nullptr, 0, 0.0f, d->dxc, d->c_up, tmp, tmp_bytes, st);
 }

@@ -1006,8 +1006,9 @@ __global__ __launch_bounds__(256) void gemm_xty2_kernel(const TI* __restrict__ x
 // out[e] = sum_c partial[c][e] in a fixed order (bitwise reproducible): 32 elements x 8 chunk groups
 // per workgroup, group g adds chunks g, g+8, ... (coalesced 128-byte reads), then the 8 group sums
 // are added in order.
+// (n, ldo: the output is [elems / n, n] with row pitch ldo; ldo == n = flat)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int64_t elems, int chunks,
-                                                               float* __restrict__ out)
+                                                               float* __restrict__ out, int n = 0, int64_t ldo = 0)
 {
     __shared__ float red[8][32];
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -1028,14 +1029,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         float t = red[0][el];
 #pragma unroll
         for (int g2 = 1; g2 < 8; ++g2) t += red[g2][el];
-        out[e] = t;
+        out[ldo > n ? (e / n) * ldo + e % n : e] = t;
     }
 }
 
 // the same sum for LARGE outputs of few chunks (dW of the deep levels: k n up to 4 M elements, <= ~16 chunks): a thread owns
 // four consecutive elements and adds the chunks in order 0, 1, 2, ... (four 16-byte loads in flight)
 __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ partial, int64_t elems, int chunks,
-                                                                    float* __restrict__ out)
+                                                                    float* __restrict__ out, int n = 0, int64_t ldo = 0)
 {
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= elems) return;
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* 
         const float4 v = p[(int64_t)c * st];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    *reinterpret_cast<float4*>(out + e) = s;
+    *reinterpret_cast<float4*>(out + (ldo > n ? (e / n) * ldo + e % n : e)) = s;      // (n % 4 == 0: a quad stays in its row)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1152,12 +1153,12 @@ int64_t colsum_chunk(int64_t m)
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // chunk sums -> out: the wide form for large outputs of few chunks, the grouped form otherwise
-void launch_reduce_partials(const float* partial, int64_t elems, int chunks, float* out, hipStream_t st)
+void launch_reduce_partials(const float* partial, int64_t elems, int chunks, float* out, hipStream_t st, int n = 0, int64_t ldo = 0)
 {
-    if (elems >= 65536 && chunks <= 64 && elems % 4 == 0 && al16(partial) && al16(out))
-        reduce_partials_wide_kernel<<<(unsigned)ws_ceil_div(elems, 1024), 256, 0, st>>>(partial, elems, chunks, out);
+    if (elems >= 65536 && chunks <= 64 && elems % 4 == 0 && al16(partial) && al16(out) && (ldo <= n || (n % 4 == 0 && ldo % 4 == 0)))
+        reduce_partials_wide_kernel<<<(unsigned)ws_ceil_div(elems, 1024), 256, 0, st>>>(partial, elems, chunks, out, n, ldo);
     else
-        reduce_partials_kernel<<<(unsigned)ws_ceil_div(elems, 32), 256, 0, st>>>(partial, elems, chunks, out);
+        reduce_partials_kernel<<<(unsigned)ws_ceil_div(elems, 32), 256, 0, st>>>(partial, elems, chunks, out, n, ldo);
 }
 
 int64_t xty_chunk(int64_t m, int k, int n)
@@ -1492,7 +1493,7 @@ int64_t ws_gemm_xty_scratch_bytes(int64_t m, int32_t k, int32_t n)
 }
 
 static int gemm_xty_core(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
-                         float* out, void* scratch, void* stream);
+                         float* out, void* scratch, void* stream, int64_t ldo = 0);
 
 int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
                 float* out, void* scratch, void* stream)
@@ -1513,13 +1514,17 @@ int ws_gemm_xty(const float* x, int64_t m, int32_t k, int64_t ldx, const float* 
 }
 
 static int gemm_xty_core(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
-                         float* out, void* scratch, void* stream)
+                         float* out, void* scratch, void* stream, int64_t ldo)
 {
+    // ldo > n: `out` is a column block of a wider matrix (row pitch ldo): the chunk sums go through the scratch buffer and the
+    // reduction writes the pitched rows (also for a single chunk, where it is the copy a caller would otherwise make)
+    const bool pitched = ldo > n;
     WS_REQUIRE(m >= 0 && k >= 1 && n >= 1 && ldx >= k && ldy >= n, "bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
     WS_REQUIRE(out, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
     if (m == 0) {
-        WS_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)k * n, st));
+        if (pitched) WS_HIP(hipMemset2DAsync(out, sizeof(float) * (size_t)ldo, 0, sizeof(float) * (size_t)n, (size_t)k, st));
+        else WS_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)k * n, st));
         return WS_OK;
     }
     WS_REQUIRE(x && y && scratch, "NULL argument");
@@ -1527,7 +1532,7 @@ static int gemm_xty_core(const float* x, int64_t m, int32_t k, int64_t ldx, cons
     const int chunks = (int)ws_ceil_div(m, chunk);
     const int vecx = al16(x) && (ldx % 4 == 0);
     const int vecy = al16(y) && (ldy % 4 == 0);
-    float* partial = chunks == 1 ? out : (float*)scratch;
+    float* partial = (chunks == 1 && !pitched) ? out : (float*)scratch;
     const bool al8x = (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && ldx % 2 == 0;
     const bool al8y = (reinterpret_cast<uintptr_t>(y) & 7u) == 0 && ldy % 2 == 0;
     if (ws_gemm_variant == 2 && chunk * (ldx > ldy ? ldx : ldy) * 4 < (1ll << 31)) {
@@ -1579,12 +1584,20 @@ static int gemm_xty_core(const float* x, int64_t m, int32_t k, int64_t ldx, cons
 #undef WS_XTY
     }
     WS_LAUNCH_CHECK();
-    if (chunks > 1) {
+    if (chunks > 1 || pitched) {
         const int64_t elems = (int64_t)k * n;
-        launch_reduce_partials(partial, elems, chunks, out, st);
+        launch_reduce_partials(partial, elems, chunks, out, st, n, pitched ? ldo : 0);
         WS_LAUNCH_CHECK();
     }
     return WS_OK;
+}
+
+// private to the library (ws_common.h): dW written as a column block of a wider matrix (row pitch ldo >= n)
+int ws_priv_gemm_xty_pitched(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy, float* out,
+                             int64_t ldo, void* scratch, void* stream)
+{
+    WS_REQUIRE(ldo >= n, "output pitch smaller than a row");
+    return gemm_xty_core(x, m, k, ldx, y, n, ldy, out, scratch, stream, ldo);
 }
 
 

@@ -54,6 +54,9 @@ extern "C" int ws_priv_gemm_xb_ex(const float* x, int64_t m, int32_t k, int64_t 
                                   int64_t res_rows_ld, int64_t res_nrows, int32_t act, float slope, float drop_p, uint64_t drop_seed,
                                   float* y, int64_t ldy, void* scratch, int64_t scratch_bytes, void* stream);   // gemm.hip for blocks.hip
 
+extern "C" int ws_priv_gemm_xty_pitched(const float* x, int64_t m, int32_t k, int64_t ldx, const float* y, int32_t n, int64_t ldy,
+                                        float* out, int64_t ldo, void* scratch, void* stream);                        // gemm.hip for blocks.hip
+
 // grid size for wave-per-item / grid-stride kernels: enough workgroups to fill 256 CUs a few
 // times over, never more than the work.
 static inline int ws_grid(int64_t items, int per_block, int max_blocks = 256 * 16)
