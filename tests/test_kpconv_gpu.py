@@ -382,3 +382,49 @@ def test_gemm_staged_epilogue_is_bit_identical(gpu, m, k, n):
     assert torch.equal(outs[0], outs[1])
     want = torch.nn.functional.leaky_relu((x.double() @ b.double()) + bias.double() + res.double(), 0.1)
     assert float((outs[1].double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n", [(40003, 9, 128), (400000, 45, 64), (5000, 7, 4), (4096, 64 - 1, 192), (33333, 3, 1024)])
+def test_gemm_shallow_contractions_stream(gpu, m, k, n):
+    """gemm_xb_shallow_kernel (k <= 64 not a multiple of 32: the logits' dX, the input layer's contraction) against float64, with
+    bias + residual + LeakyReLU and with the LeakyReLU' gate + dropout of ws_gemm_xb_gate_dropout; and against gemm_xb_kernel
+    (switch off) on the same inputs"""
+    import ctypes as C
+    from weasal_amd import _lib
+    from weasal_amd._lib import check, current_stream, ptr
+    lib = _lib.lib()
+    torch.manual_seed(m + k)
+    x = torch.randn(m, k, device=gpu)
+    b = torch.randn(k, n, device=gpu)
+    bias = torch.randn(n, device=gpu)
+    res = torch.randn(m, n, device=gpu)
+    flag = C.c_int.in_dll(lib, "ws_gemm_shallow")
+    outs = []
+    try:
+        for v in (1, 0):
+            flag.value = v
+            y = torch.full((m, n), float("nan"), device=gpu)
+            check(lib.ws_gemm_xb_epilogue(ptr(x), m, k, k, ptr(b), n, ptr(bias), ptr(res), n, 1, 0.1, ptr(y), n, current_stream()))
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        flag.value = 1
+    want = torch.nn.functional.leaky_relu((x.double() @ b.double()) + bias.double() + res.double(), 0.1)
+    scale = float(want.abs().max())
+    assert bool(torch.isfinite(outs[0]).all())
+    assert float((outs[0].double() - want).abs().max()) <= 1e-5 * scale
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * scale
+    # gate + dropout form: dropout_bwd first, then the gate (the order of the separate passes)
+    gy = torch.randn(m, n, device=gpu)
+    p, seed = 0.5, 13579
+    plain = torch.empty((m, n), device=gpu)
+    check(lib.ws_gemm_xb_epilogue(ptr(x), m, k, k, ptr(b), n, None, None, 0, 0, 0.0, ptr(plain), n, current_stream()))
+    dropped = torch.empty_like(plain)
+    check(lib.ws_dropout_apply(ptr(plain), plain.numel(), p, seed, ptr(dropped), current_stream()))
+    ref = dropped * torch.where(gy > 0, torch.ones_like(gy), torch.full_like(gy, 0.1))
+    got = torch.full((m, n), float("nan"), device=gpu)
+    scratch = torch.empty(256, dtype=torch.uint8, device=gpu)
+    check(lib.ws_gemm_xb_gate_dropout(ptr(x), m, k, k, ptr(b), n, ptr(gy), n, 0.1, p, seed, ptr(got), n, ptr(scratch), 0, current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)

@@ -464,6 +464,95 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
         xb_rows_epilogue<NT>(acc, row, m, n0 + wn * (32 * NT), n, h, y, ldy, bias, residual, ldr, act, slope, gate);
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_xb_shallow: Y = act(X [m, k] @ B [k, n] + bias + residual) for contractions too shallow and ragged for the MFMA tiles
+// (k = 9: the logits' dX; k = 45: the 3-channel input layer's contraction).  The arithmetic is nothing (k FMAs per output); what
+// matters is that the output -- all of the traffic -- leaves as whole 128-byte row segments and that the epilogue menu
+// (residual, bias, LeakyReLU, gates) is the float4 one.  Thread = 4 consecutive columns of one row: the k values of its row
+// come from L1 (the n / 4 threads of a row read the same addresses), the 4 columns of B from LDS (one ds_read_b128 per k,
+// the same address for all rows of a wave's column); sequential fmaf over k (fixed order).  gemm_xb_kernel's scalar
+// epilogue took 90-96 us on these shapes at M = 400 000, 3-4 x their streaming time.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_xb_shallow_kernel(const float* __restrict__ x, int64_t m, int k, int64_t ldx,
+                                                               const float* __restrict__ b, int n, float* __restrict__ y, int64_t ldy,
+                                                               const float* __restrict__ bias, const float* __restrict__ residual,
+                                                               int64_t ldr, int act, float slope, const XbGate gate, int rows_per_wg)
+{
+    // LDS: B as [kp][n] (kp = k rounded up to 4, the extra rows zero) and the workgroup's rows of X as [rows_per_wg][kp] (each
+    // element of X loaded once, coalesced; a thread then takes four k of its row per ds_read_b128 -- through global loads the
+    // n / 4 threads of a row each issued the same k dword loads: address-unit bound, 121 us on the 45-deep shape)
+    extern __shared__ __attribute__((aligned(16))) float shallow_lds[];
+    const int kp = (k + 3) & ~3;
+    float* bs = shallow_lds;
+    float* xs = shallow_lds + kp * n;
+    const int t = threadIdx.x;
+    for (int e = t; e < kp * n / 4; e += 256)
+        reinterpret_cast<float4*>(bs)[e] = e < k * n / 4 ? reinterpret_cast<const float4*>(b)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = r0 + rows_per_wg < m ? r0 + rows_per_wg : m;
+    const int nrows = (int)(r1 - r0);
+    {   // (row, k) of element e = t + 256 i, advanced without a division per element
+        int r = t / kp, kk = t - r * kp;
+        const int dr = 256 / kp, dk = 256 - dr * kp;
+        for (int e = t; e < nrows * kp; e += 256) {
+            xs[e] = kk < k ? x[(r0 + r) * ldx + kk] : 0.0f;
+            r += dr; kk += dk;
+            if (kk >= kp) { kk -= kp; ++r; }
+        }
+    }
+    __syncthreads();
+    const int n4 = n >> 2;
+    const int per = 256 / n4;                              // rows per pass (n4 <= 256)
+    const int c = (t % n4) * 4, rl = t / n4;
+    if (rl >= per) return;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bq = *reinterpret_cast<const float4*>(bias + c);
+    // four rows per thread and trip (rows r, r + per, r + 2 per, r + 3 per): one read of the B quad serves four rows -- with one
+    // row per trip the kernel was bound by LDS bandwidth (5 ds_read_b128 per 16 FMAs)
+    for (int rb = rl; rb < nrows; rb += 4 * per) {
+        float4 v[4];
+        const float* xr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int r = rb + u * per;
+            xr[u] = xs + (r < nrows ? r : rb) * kp;              // (rows past the end: recomputed, never stored)
+        }
+        for (int kk = 0; kk < kp; kk += 4) {
+            const float4 w0 = *reinterpret_cast<const float4*>(&bs[kk * n + c]);
+            const float4 w1 = *reinterpret_cast<const float4*>(&bs[(kk + 1) * n + c]);
+            const float4 w2 = *reinterpret_cast<const float4*>(&bs[(kk + 2) * n + c]);
+            const float4 w3 = *reinterpret_cast<const float4*>(&bs[(kk + 3) * n + c]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 a = *reinterpret_cast<const float4*>(xr[u] + kk);
+                v[u].x = fmaf(a.x, w0.x, v[u].x); v[u].y = fmaf(a.x, w0.y, v[u].y); v[u].z = fmaf(a.x, w0.z, v[u].z); v[u].w = fmaf(a.x, w0.w, v[u].w);
+                v[u].x = fmaf(a.y, w1.x, v[u].x); v[u].y = fmaf(a.y, w1.y, v[u].y); v[u].z = fmaf(a.y, w1.z, v[u].z); v[u].w = fmaf(a.y, w1.w, v[u].w);
+                v[u].x = fmaf(a.z, w2.x, v[u].x); v[u].y = fmaf(a.z, w2.y, v[u].y); v[u].z = fmaf(a.z, w2.z, v[u].z); v[u].w = fmaf(a.z, w2.w, v[u].w);
+                v[u].x = fmaf(a.w, w3.x, v[u].x); v[u].y = fmaf(a.w, w3.y, v[u].y); v[u].z = fmaf(a.w, w3.z, v[u].z); v[u].w = fmaf(a.w, w3.w, v[u].w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb + u * per;
+            if (r >= nrows) break;
+            const int64_t row = r0 + r;
+            float4 o = v[u];
+            if (residual) {
+                const float* rrow = xb_res_row(residual, ldr, gate, row);
+                if (rrow) { const float4 rq = *reinterpret_cast<const float4*>(rrow + c); o.x += rq.x; o.y += rq.y; o.z += rq.z; o.w += rq.w; }
+            }
+            o.x += bq.x; o.y += bq.y; o.z += bq.z; o.w += bq.w;
+            if (act) {
+                o.x = o.x > 0.0f ? o.x : o.x * slope; o.y = o.y > 0.0f ? o.y : o.y * slope;
+                o.z = o.z > 0.0f ? o.z : o.z * slope; o.w = o.w > 0.0f ? o.w : o.w * slope;
+            }
+            if (gate.y || gate.mask || gate.drop.on) xb_gate4(o, gate, row, c);
+            *reinterpret_cast<float4*>(y + row * ldy + c) = o;
+        }
+    }
+}
+
 // The three-way bf16 split products (gemm_xb3, gemm_xty2<..., SPLIT>) are a LAB build only (-DWS_LAB_SPLIT_GEMM; tools/
 // split_gemm_lab.py): measured in round 2 (15 % per product, 2.3 % per step, fp32-accurate), not the reference's
 // arithmetic behind a line that says f32 -- they are not compiled into the product library.
@@ -1192,6 +1281,7 @@ extern "C" {
 // diagnostic switches of tools/gemm_lab.cpp (not part of the drop-in surface of include/weasal_hip.h)
 int ws_gemm_wave_cols = 0;  // forced wave grid of gemm_xb2 (column groups 1 / 2), 0 = automatic
 int ws_gemm_thin_k = 64;    // products with k <= this take 64-column tiles (more, lighter workgroups: they are all prologue and epilogue) instead of 128
+int ws_gemm_shallow = 1;     // products with k <= 64 that the MFMA tiles do not take (k % 32 != 0), n % 4 == 0, many rows: 1 = gemm_xb_shallow_kernel, 0 = gemm_xb_kernel
 int ws_gemm_staged = 1;     // gemm_xb2 epilogue: 1 = the tile turned through LDS (whole 128-byte row segments per store), 0 = per-lane rows
 int ws_gemm_variant = 2;    // 1 = LDS-staged tiles (gemm_xb / gemm_xty), 2 = operands straight from global memory
 #ifdef WS_LAB_SPLIT_GEMM
@@ -1330,6 +1420,18 @@ static int gemm_xb_core(const float* x, int64_t m, int32_t k, int64_t ldx, const
     }
     WS_REQUIRE(bcs == 1 && brs == n, "a strided small matrix needs k %% 32 == 0, n %% 4 == 0 and 16-byte aligned rows "
                                      "(k=%d n=%d): pass a row-major [K,N] copy for this shape", k, n);
+    if (ws_gemm_shallow && k <= 64 && n % 4 == 0 && n <= 1024 && (int64_t)k * n <= 8192 && m >= 4096 && al16(b) && al16(y) && ldy % 4 == 0 &&
+        (!residual || (al16(residual) && ldr % 4 == 0)) && (!bias || al16(bias)) && (!gate.y || (al16(gate.y) && gate.ld % 4 == 0)) &&
+        (!gate.mask || ((reinterpret_cast<uintptr_t>(gate.mask) & 3u) == 0 && gate.ldm % 4 == 0))) {
+        // shallow, ragged contraction over many rows: the streaming VALU form (gemm_xb_shallow_kernel)
+        const int per = 256 / (n / 4);
+        const int kp = (k + 3) & ~3;
+        int rows = per * 8;                                             // 8 row passes per workgroup
+        gemm_xb_shallow_kernel<<<(unsigned)ws_ceil_div(m, rows), 256, sizeof(float) * ((size_t)kp * n + (size_t)rows * kp), st>>>(
+            x, m, k, ldx, b, n, y, ldy, bias, residual, ldr, act, slope, gate, rows);
+        WS_LAUNCH_CHECK();
+        return WS_OK;
+    }
     if (n <= 32) {
         gemm_xb_kernel<1, 32><<<dim3((unsigned)gx, 1), 256, 0, st>>>(x, m, k, ldx, b, n, n, y, ldy, vecx, vecb, bias, residual, ldr,
                                                                  act, slope, gate);

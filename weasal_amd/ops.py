@@ -724,9 +724,10 @@ class _MatmulEpilogue(torch.autograd.Function):
             dz, dbias = _act_bwd_colsum(dy, y if ctx.slope is not None else None, ctx.slope, want_bias)
         dx = db = dres = None
         if li is not None:
-            # (only on the rows-on-lanes MFMA kernel, whose epilogue reads the gate rows 16 bytes per lane: through the scalar
-            # epilogue of the shallow-product kernel the 9-logit dX took 247 instead of 96 us with the gate on it)
-            li.pregated = bool(ctx.needs_input_grad[0]) and dz.shape[1] % 32 == 0 and b.shape[0] % 4 == 0
+            # (on the kernels whose epilogue reads the gate rows 16 bytes per lane: the rows-on-lanes MFMA kernel and the
+            # streaming form of shallow contractions -- through gemm_xb_kernel's scalar epilogue the 9-logit dX took 247
+            # instead of 96 us with the gate on it)
+            li.pregated = bool(ctx.needs_input_grad[0]) and (dz.shape[1] % 32 == 0 or dz.shape[1] <= 64) and b.shape[0] % 4 == 0
         if ctx.needs_input_grad[0]:
             if li is not None and li.pregated:
                 # dx = dropout_bwd(dz @ b^T) * LeakyReLU'(x): x is the producer's activated (and dropped) output
