@@ -175,3 +175,37 @@ def test_contrast_rows_small_slice_and_wide_logits():
     assert float((loss.detach().double() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
     loss.sum().backward()
     assert bool(torch.isfinite(on.grad).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nc,nf,c", [(7000, 40000, 128), (300, 5000, 256), (1, 77, 64), (5000, 5000, 32), (900, 3000, 20), (280, 1500, 1024), (1500, 10000, 512)])
+def test_closest_pool_backward_vector_form(gpu, nc, nf, c):
+    """nearest-upsampling backward with float4 lanes and several incoming rows side by side (closest_pool_bwd_vec_kernel) against
+    index_add in float64 and against the scalar kernel: shadow indices, supports nobody points at, one support for everything"""
+    import ctypes as C
+    from weasal_amd import _lib, ops
+    lib = _lib.lib()
+    torch.manual_seed(nc + c)
+    x = torch.randn(nc, c, device=gpu, requires_grad=True)
+    ups = torch.randint(0, nc, (nf, 4), device=gpu)
+    if nc > 10:
+        ups[:, 0] = torch.where(ups[:, 0] % 5 == 0, torch.full_like(ups[:, 0], 3), ups[:, 0])     # a crowded support, empty ones
+    ups[::13, 0] = nc                                                                              # shadow rows
+    g = torch.randn(nf, c, device=gpu)
+    flag = C.c_int.in_dll(lib, "ws_closest_bwd_vec")
+    grads = []
+    try:
+        for v in (1, 0):
+            flag.value = v
+            ops.clear_table_cache()
+            y = ops.closest_pool(x, ups)
+            (dx,) = torch.autograd.grad(y, x, g)
+            torch.cuda.synchronize()
+            grads.append(dx)
+    finally:
+        flag.value = 1
+    real = ups[:, 0] < nc
+    want = torch.zeros(nc, c, device=gpu, dtype=torch.float64).index_add_(0, ups[real, 0], g[real].double())
+    scale = float(want.abs().max()) + 1e-30
+    assert float((grads[0].double() - want).abs().max()) <= 1e-5 * scale
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale

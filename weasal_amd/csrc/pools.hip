@@ -257,9 +257,55 @@ __global__ __launch_bounds__(256) void closest_pool_bwd_kernel(const T* __restri
 }
 
 
+// float rows of c = 4 G channels, G | 64: G lanes x float4 per incoming row, S = 64 / G rows of a support in flight side by side
+// (and two trips unrolled), the S partial sums added in a fixed order at the end.  The scalar form above walks a support's
+// fine points one dependent 4-byte-per-lane load at a time: 95 us for the 400 000 -> 71 000 level of the DALES step.
+template <int G>
+__global__ __launch_bounds__(256) void closest_pool_bwd_vec_kernel(const float* __restrict__ dy, int h, int c,
+                                                                    const int32_t* __restrict__ t_offsets,
+                                                                    const int32_t* __restrict__ t_pairs, int64_t ns,
+                                                                    float* __restrict__ dx)
+{
+    constexpr int S = 64 / G;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = lane % G, slot = lane / G;
+    for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < ns; s += (int64_t)gridDim.x * 4) {
+        const int beg = t_offsets[s], end = t_offsets[s + 1];
+        for (int c0 = 0; c0 < c; c0 += 4 * G) {              // (G < 64: c = 4 G, one trip; G = 64: 256 channels per trip)
+            const int ch = c0 + 4 * j;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int p = beg + slot;
+            for (; p + S < end; p += 2 * S) {
+                const int pa = t_pairs[p], pb = t_pairs[p + S];
+                const int qa = pa / h, qb = pb / h;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a;
+                if (pa - qa * h == 0) a = *reinterpret_cast<const float4*>(dy + (int64_t)qa * c + ch);
+                if (pb - qb * h == 0) b4 = *reinterpret_cast<const float4*>(dy + (int64_t)qb * c + ch);
+                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                acc.x += b4.x; acc.y += b4.y; acc.z += b4.z; acc.w += b4.w;
+            }
+            if (p < end) {
+                const int pa = t_pairs[p];
+                const int qa = pa / h;
+                if (pa - qa * h == 0) {
+                    const float4 a = *reinterpret_cast<const float4*>(dy + (int64_t)qa * c + ch);
+                    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                }
+            }
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+                acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+            }
+            if (slot == 0) *reinterpret_cast<float4*>(dx + s * c + ch) = acc;
+        }
+    }
+}
+
 // workgroups per XCD of the interleaved assignment (0 = contiguous chunks; A/B switch WEASAL_POOL_INTERLEAVE).  Level-0 max-pool
 // of the DALES step (71 000 x 59 rows of 512 bytes): forward 245 -> 195 us in the step, 136 -> 97 us alone (tools/pool_lab.py)
 extern "C" int ws_pool_interleave = 256;
+extern "C" int ws_closest_bwd_vec = 1;      // nearest-upsampling backward: 1 = float4 lanes, several incoming rows side by side (A/B: WEASAL_CLOSEST_BWD_VEC)
 static inline int pool_grid(int64_t groups, int ilv)
 {
     if (ilv <= 0) return ws_grid(groups, 4);
@@ -355,6 +401,22 @@ int closest_pool_bwd_impl(const T* dy, int64_t nq, int32_t h, int32_t c, const i
     WS_REQUIRE(ns >= 0 && nq >= 0 && c >= 1 && h >= 1, "bad sizes");
     if (ns == 0) return WS_OK;
     WS_REQUIRE(t_offsets && dx && (nq == 0 || (dy && t_pairs)), "NULL argument");
+    if constexpr (sizeof(T) == 4) {
+        const bool al = ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15u) == 0;
+        const float* dyf = reinterpret_cast<const float*>(dy);
+        float* dxf = reinterpret_cast<float*>(dx);
+        hipStream_t st = (hipStream_t)stream;
+#define WS_CPB(GV) closest_pool_bwd_vec_kernel<GV><<<ws_grid(ns, 4), 256, 0, st>>>(dyf, h, c, t_offsets, t_pairs, ns, dxf)
+        if (ws_closest_bwd_vec && al && (c == 32 || c == 64 || c == 128 || c % 256 == 0)) {
+            if (c == 32) WS_CPB(8);
+            else if (c == 64) WS_CPB(16);
+            else if (c == 128) WS_CPB(32);
+            else WS_CPB(64);
+            WS_LAUNCH_CHECK();
+            return WS_OK;
+        }
+#undef WS_CPB
+    }
     closest_pool_bwd_kernel<T><<<ws_grid(ns, 4), 256, 0, (hipStream_t)stream>>>(dy, h, c, t_offsets, t_pairs, ns, dx);
     WS_LAUNCH_CHECK();
     return WS_OK;
