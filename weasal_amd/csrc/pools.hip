@@ -47,8 +47,10 @@ template <int G, typename T, typename AT = int32_t>
 __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restrict__ x, int64_t ns, int c,
                                                                 const int64_t* __restrict__ inds, int64_t nq, int h,
                                                                 T* __restrict__ out, AT* __restrict__ arg,
-                                                                const int32_t* __restrict__ order = nullptr, int ilv = 0)
+                                                                const int32_t* __restrict__ order = nullptr, int ilv = 0, int split = 1)
 {
+    // split > 1 (wide rows of few queries: the deep levels): a group = (query, one 4 G-channel chunk) instead of a query with
+    // its chunks one after the other -- 275 queries x 1 024 channels are 1 100 independent waves instead of 275 four times as long
     // order (optional): a spatially coherent permutation of the queries (the cell order of their level's search).  The
     // pooled points come out of the grid subsampling in hash-table order: walked by index, consecutive queries gather
     // rows from all over the cloud and every 512-byte row is fetched ~3.6 times from HBM (PMC, round 2); in cell order
@@ -57,12 +59,14 @@ __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restri
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane % G, slot = lane / G;
     int64_t g0, gstep, gend;
-    pool_groups(ws_ceil_div_dev(nq, S), ilv, wave, g0, gstep, gend);
+    pool_groups(ws_ceil_div_dev(nq, S) * split, ilv, wave, g0, gstep, gend);
     for (int64_t grp = g0; grp < gend; grp += gstep) {
-        const int64_t qi = grp * S + slot;
+        const int64_t qi = (grp / split) * S + slot;
         const bool qok = qi < nq;
         const int64_t q = (qok && order) ? (int64_t)order[qi] : qi;
-        for (int c0 = 0; c0 < c; c0 += 4 * G) {
+        const int cbeg = split > 1 ? (int)(grp % split) * (4 * G) : 0;
+        const int cend = split > 1 ? min(cbeg + 4 * G, c) : c;
+        for (int c0 = cbeg; c0 < cend; c0 += 4 * G) {
             const int ch = c0 + 4 * j;
             const bool ok = qok && ch < c;
             float4 best = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
@@ -131,20 +135,23 @@ __global__ __launch_bounds__(256) void max_pool_bwd_vec_kernel(const T* __restri
                                                                 int h, int c, const int32_t* __restrict__ t_offsets,
                                                                 const int32_t* __restrict__ t_pairs, int64_t ns,
                                                                 T* __restrict__ dx, const int32_t* __restrict__ order = nullptr,
-                                                                int ilv = 0, const T* __restrict__ add = nullptr)
+                                                                int ilv = 0, const T* __restrict__ add = nullptr, int split = 1)
 {
+    // split: as in the forward -- a group = (support, one channel chunk)
     // add (same shape as dx, or NULL): a second gradient of the same rows, summed into the store -- dx = pool gradient + add
     constexpr int S = 64 / G;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane % G, slot = lane / G;
     int64_t g0, gstep, gend;
-    pool_groups(ws_ceil_div_dev(ns, S), ilv, wave, g0, gstep, gend);
+    pool_groups(ws_ceil_div_dev(ns, S) * split, ilv, wave, g0, gstep, gend);
     for (int64_t grp = g0; grp < gend; grp += gstep) {
-        const int64_t si = grp * S + slot;
+        const int64_t si = (grp / split) * S + slot;
         const bool sok = si < ns;
         const int64_t s = (sok && order) ? (int64_t)order[si] : si;       // supports in their level's cell order (see the forward)
         const int beg = sok ? t_offsets[s] : 0, end = sok ? t_offsets[s + 1] : 0;
-        for (int c0 = 0; c0 < c; c0 += 4 * G) {
+        const int cbeg = split > 1 ? (int)(grp % split) * (4 * G) : 0;
+        const int cend = split > 1 ? min(cbeg + 4 * G, c) : c;
+        for (int c0 = cbeg; c0 < cend; c0 += 4 * G) {
             const int ch = c0 + 4 * j;
             if (!(sok && ch < c)) continue;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -305,6 +312,11 @@ __global__ __launch_bounds__(256) void closest_pool_bwd_vec_kernel(const float* 
 // workgroups per XCD of the interleaved assignment (0 = contiguous chunks; A/B switch WEASAL_POOL_INTERLEAVE).  Level-0 max-pool
 // of the DALES step (71 000 x 59 rows of 512 bytes): forward 245 -> 195 us in the step, 136 -> 97 us alone (tools/pool_lab.py)
 extern "C" int ws_pool_interleave = 256;
+extern "C" int ws_pool_split_rows = 8192;   // max-pools over fewer rows than this give every 256-channel chunk of a row a wave of its own (0 = never)
+static int pool_split(int64_t rows, int c)
+{
+    return (ws_pool_split_rows > 0 && rows < ws_pool_split_rows && c > 256) ? (int)ws_ceil_div(c, 256) : 1;
+}
 extern "C" int ws_closest_bwd_vec = 1;      // nearest-upsampling backward: 1 = float4 lanes, several incoming rows side by side (A/B: WEASAL_CLOSEST_BWD_VEC)
 static inline int pool_grid(int64_t groups, int ilv)
 {
@@ -327,7 +339,10 @@ int max_pool_fwd_impl(const T* x, int64_t ns, int32_t c, const int64_t* inds, in
     else if (vec && c <= 32) max_pool_fwd_vec_kernel<8, T><<<pool_grid(ws_ceil_div(nq, 8), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     else if (vec && c <= 64) max_pool_fwd_vec_kernel<16, T><<<pool_grid(ws_ceil_div(nq, 4), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     else if (vec && c <= 128) max_pool_fwd_vec_kernel<32, T><<<pool_grid(ws_ceil_div(nq, 2), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
-    else if (vec) max_pool_fwd_vec_kernel<64, T><<<pool_grid(nq, ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (vec) {
+        const int sp = pool_split(nq, c);
+        max_pool_fwd_vec_kernel<64, T><<<pool_grid(nq * sp, ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv, sp);
+    }
     else max_pool_fwd_kernel<T><<<ws_grid(nq, 4), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg);
     WS_LAUNCH_CHECK();
     return WS_OK;
@@ -347,7 +362,10 @@ int max_pool_bwd_impl(const T* dy, const int32_t* arg, int64_t nq, int32_t h, in
     if (vec && c <= 32) max_pool_bwd_vec_kernel<8, T><<<pool_grid(ws_ceil_div(ns, 8), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
     else if (vec && c <= 64) max_pool_bwd_vec_kernel<16, T><<<pool_grid(ws_ceil_div(ns, 4), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
     else if (vec && c <= 128) max_pool_bwd_vec_kernel<32, T><<<pool_grid(ws_ceil_div(ns, 2), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
-    else if (vec) max_pool_bwd_vec_kernel<64, T><<<pool_grid(ns, ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv);
+    else if (vec) {
+        const int sp = pool_split(ns, c);
+        max_pool_bwd_vec_kernel<64, T><<<pool_grid(ns * sp, ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, nullptr, sp);
+    }
     else max_pool_bwd_kernel<T><<<ws_grid(ns, 4), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx);
     WS_LAUNCH_CHECK();
     return WS_OK;
@@ -363,7 +381,10 @@ int max_pool_fwd_u8_impl(const float* x, int64_t ns, int32_t c, const int64_t* i
     else if (c <= 32) max_pool_fwd_vec_kernel<8, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 8), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     else if (c <= 64) max_pool_fwd_vec_kernel<16, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 4), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     else if (c <= 128) max_pool_fwd_vec_kernel<32, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 2), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
-    else max_pool_fwd_vec_kernel<64, float, uint8_t><<<pool_grid(nq, ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else {
+        const int sp = pool_split(nq, c);
+        max_pool_fwd_vec_kernel<64, float, uint8_t><<<pool_grid(nq * sp, ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv, sp);
+    }
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
@@ -377,7 +398,10 @@ int max_pool_bwd_u8_impl(const float* dy, const uint8_t* arg, int64_t nq, int32_
     if (c <= 32) max_pool_bwd_vec_kernel<8, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 8), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add);
     else if (c <= 64) max_pool_bwd_vec_kernel<16, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 4), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add);
     else if (c <= 128) max_pool_bwd_vec_kernel<32, float, uint8_t><<<pool_grid(ws_ceil_div(ns, 2), ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add);
-    else max_pool_bwd_vec_kernel<64, float, uint8_t><<<pool_grid(ns, ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add);
+    else {
+        const int sp = pool_split(ns, c);
+        max_pool_bwd_vec_kernel<64, float, uint8_t><<<pool_grid(ns * sp, ilv), 256, 0, st>>>(dy, arg, h, c, t_offsets, t_pairs, ns, dx, order, ilv, add, sp);
+    }
     WS_LAUNCH_CHECK();
     return WS_OK;
 }
