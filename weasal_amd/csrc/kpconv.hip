@@ -43,6 +43,9 @@ struct GeomParams {
                           // ws_kpconv_deform_prepare: a pair farther apart than that + extent has no influence (NULL: no bound)
     int cut;              // pool-form K3 (MODE 0): 1 = rows are sorted by distance, stop at the influence reach (see CUT)
     int ilv;              // K4G: workgroups per XCD of the interleaved item assignment (ws_wave_items), 0 = contiguous chunks
+    int csplit;           // matrix-core K3 (rigid): > 1 = an item is (query, one of csplit runs of channel blocks) instead of a query
+                          // with all its blocks one after the other -- few queries with wide rows (the deep levels: 275 x 512)
+                          // otherwise leave most SIMDs without a wave; the influences are recomputed per block either way
 };
 
 // Influence of the K kernel points on one neighbour offset n = s - q.  kp is wave-uniform.
@@ -674,8 +677,9 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     const float e2 = g.extent * g.extent;
     const bool haskp = i < K;
 
+    const int csplit = (FUSE || MODE != 0 || g.csplit < 1) ? 1 : g.csplit;      // items per query (see GeomParams::csplit)
     int64_t ibeg, iend;
-    ws_block_range(nq, ibeg, iend);
+    ws_block_range(nq * csplit, ibeg, iend);
 
     float kx = 0.f, ky = 0.f, kz = 0.f;
     if (!DEF && haskp) { kx = kernel_points[3 * i]; ky = kernel_points[3 * i + 1]; kz = kernel_points[3 * i + 2]; }
@@ -719,7 +723,8 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
     int iter = 0;
     auto item_v = [&](int64_t it) -> int {                        // query of item `it`, in a VGPR (clamped past the end)
         const int64_t itc = it < iend ? it : iend - 1;
-        return order ? order[itc + vz] : (int)itc + vz;
+        const int64_t qi = csplit > 1 ? itc / csplit : itc;
+        return order ? order[qi + vz] : (int)qi + vz;
     };
     const int col0 = lane < h ? lane : 0;
     auto raw_idx = [&](int qv) -> int64_t {
@@ -770,6 +775,13 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
             const float* kp = deformed_kp + q * (3 * K) + 3 * i;
             kx = kp[0]; ky = kp[1]; kz = kp[2];
         }
+        // channel blocks of this item: all of them, or the item's run of whole blocks
+        int cb_lo = 0, cb_hi = ci;
+        if (csplit > 1) {
+            const int run = ((ci + CB * csplit - 1) / (CB * csplit)) * CB;
+            cb_lo = (int)(item % csplit) * run;
+            cb_hi = min(ci, cb_lo + run);
+        }
         float mind = 3.4e38f;
         float cut2 = cut2_rigid, rk = 0.0f, rq = 0.0f;
         if constexpr (CUT && MODE == 2) {
@@ -777,7 +789,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_fwd_mfma_kernel(
             rq = group_max(rk) + g.extent;                            // beyond it: no influence
             cut2 = 3.4e38f;                                           // the first chunk is walked in full (min_d2 needs a start)
         }
-        for (int cb = 0; cb < ci; cb += CB) {
+        for (int cb = cb_lo; cb < cb_hi; cb += CB) {
             f32x4v acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -2119,6 +2131,8 @@ extern "C" int ws_kpconv_gs;              // diagnostics: > 0 forces the group s
 int ws_kpconv_gs = 0;
 extern "C" int ws_kpconv_grid_rows;       // diagnostics: 0 = K4G always walks the cell grid (WEASAL_K4G_ROWS=0)
 int ws_kpconv_grid_rows = 1;
+extern "C" int ws_kpconv_split_nt = 4;        // ... with at most this many channels per lane (blocks of 16 x this many channels)
+extern "C" int ws_kpconv_split_rows = 4096;   // matrix-core K3 on fewer queries than this: one item per (query, channel block) (0 = never; WEASAL_K3_SPLIT_ROWS)
 extern "C" int ws_kpconv_grid_sorted;     // 1: ws_kpconv_gather_bwd_x_grid sums the incoming pairs in index order (the pair order of
 extern "C" int ws_kpconv_k6_interleave = 0;       // the same for the geometry backward on the matrix core (WEASAL_K6_INTERLEAVE)
 extern "C" int ws_kpconv_gridw_interleave = 512;    // the same for the wide-row K4G of config 5 (WEASAL_K4GW_INTERLEAVE)
@@ -2143,7 +2157,7 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
     GeomParams g{extent, influence, aggregation, deformed_kp ? 1 : 0, ws_kpconv_ablate, nullptr, 0.0f, nullptr, 0, nullptr, nullptr,
                  rows_sorted ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
-    const int grid = ws_grid(nq, 4);
+    int grid = ws_grid(nq, 4);
     WS_REQUIRE(ns * (int64_t)ci < (1ll << 31), "ns*ci exceeds the 32-bit row offsets of the gather");
     const int vec4 = (ci % 4 == 0) && ws_row_aligned<T>(x) && ws_row_aligned<T>(wf);
     WS_REQUIRE(F32 || vec4, "bf16 feature rows need ci %% 4 == 0 and 8-byte aligned rows (ci=%d)", ci);
@@ -2155,6 +2169,13 @@ int gather_fwd_impl(const float* q_pts, int64_t nq, const float* s_pts, int64_t 
         bool vecrow = (ci % nt == 0) && (nt == 1 || al16);
         if (!vecrow) nt = 1;
         if (nt == 1) vecrow = true;       // one channel per lane: any ci, any alignment (lanes past ci are masked)
+        if (fastm && !rows_sorted && ws_kpconv_split_rows > 0 && nq < ws_kpconv_split_rows && vecrow && nt > ws_kpconv_split_nt && ws_kpconv_split_nt > 0 &&
+            ci % ws_kpconv_split_nt == 0)
+            nt = ws_kpconv_split_nt;                              // narrower blocks: more items per query
+        if (fastm && !rows_sorted && ws_kpconv_split_rows > 0 && nq < ws_kpconv_split_rows && ci > 16 * nt) {
+            g.csplit = (ci + 16 * nt - 1) / (16 * nt);           // one channel block per item
+            grid = ws_grid(nq * g.csplit, 4);
+        }
 #define WS_FWDM2(NTV, MODEV, DEFV)                                                                                  \
     kpconv_gather_fwd_mfma_kernel<NTV, MODEV, DEFV, true, T><<<grid, 256, 0, st>>>(q_pts, nq, s_pts, ns, inds, h, x, ci, \
                                                                                    kernel_points, deformed_kp, modulations, g, wf, min_d2, order)
