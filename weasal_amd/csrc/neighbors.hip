@@ -897,16 +897,19 @@ struct KeyLastGuard {
 
 // lab switches (tools/k1_lab.py): grid cap and queries per workgroup of the fill launch
 extern "C" int ws_nb_wide_caps = 1;       // 1: slab of the wide asynchronous search sized to the width (576 / 704 / 1024), 0: always 1024 (A/B: WEASAL_NB_WIDE_CAPS)
-// grid cap of the fill launch.  1 024 workgroups (4 per CU: the fill's queries are walked in cell order either way) instead of
+// grid cap of the fill launch on the ASYNCHRONOUS entries (the pyramid builders; the synchronous drop-in entries keep 4 096).  1 024 workgroups (4 per CU: the fill's queries are walked in cell order either way) instead of
 // 4 096: alone the 13 searches of a pyramid take 1.29 instead of 1.08 ms (tools/k1_lab2.py), but they run under the training
 // stream, which gets wave slots back -- DALES step 13.53 -> 13.42 ms, inference 5.20 -> 5.09 ms, config 5 38.7 -> 38.4 ms (A/B: WEASAL_NB_MAX_BLOCKS, 0 = 4 096)
 extern "C" int ws_nb_max_blocks = 1024;
 extern "C" int ws_nb_queries_per_block = 0;
 
+// beside: the call comes through the asynchronous entries, i.e. from a pyramid builder working beside a training stream: the
+// grid cap above applies; the synchronous entries (the drop-in `batch_query` and plan / fill) have the GPU to themselves: 4 096
 static int nb_launch_fill(ws_neighbors_ws* ws, int cap, int32_t width, int32_t* out_i32, int64_t* out_i64,
-                          bool with_counts, hipStream_t st)
+                          bool with_counts, hipStream_t st, bool beside = false)
 {
-    const int grid = ws_grid(ws->nq, ws_nb_queries_per_block > 0 ? ws_nb_queries_per_block : 4, ws_nb_max_blocks > 0 ? ws_nb_max_blocks : 256 * 16);
+    const int grid = ws_grid(ws->nq, ws_nb_queries_per_block > 0 ? ws_nb_queries_per_block : 4,
+                             (beside && ws_nb_max_blocks > 0) ? ws_nb_max_blocks : 256 * 16);
     const int32_t* qo = ws->self_query ? ws->order.p : nullptr;
     int32_t* cn = with_counts ? ws->counts.p : nullptr;
     int32_t* mx = with_counts ? ws->max_count_word : nullptr;
@@ -1000,7 +1003,7 @@ int ws_radius_neighbors_search_async(ws_neighbors_ws* ws, const float* queries, 
     // rows wider than the 128-entry fast path are asked for (deformable radius): the 1024-key bucketed sort from the start,
     // instead of a 128-entry pass the caller would have to repeat
     const int cap = ws_radius_neighbors_async_cap(width);
-    if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st))) return rc;   // max-count word cleared by nb_prepare
+    if ((rc = nb_launch_fill(ws, cap, width, out_i32, out_i64, true, st, true))) return rc;   // max-count word cleared by nb_prepare
     WS_HIP(hipMemcpyAsync(d_max_count, ws->max_count_word, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     ws->max_count_host = cap;   // unknown on the host; rows beyond the slab are reported through d_max_count
     return WS_OK;
