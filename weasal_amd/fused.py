@@ -12,6 +12,7 @@ CPU oracle mode).
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -157,6 +158,8 @@ class GateLink:
     __slots__ = ("out", "pregated", "drop", "slope")
 
     def __init__(self):
+        # out: a WEAK reference to the producer's output -- the link hangs off that tensor's own autograd node (ctx.geom /
+        # ctx.links), so a strong one would close a cycle only the cyclic collector could free (0.7 GB per DALES step)
         self.out, self.pregated = None, False
         self.drop = None            # (p, seed) when the producer's output went through its fused dropout: the gate undoes it too
         self.slope = 0.1            # the producer's LeakyReLU slope
@@ -181,7 +184,7 @@ def linear_links_done(batch, links, out, relu):
 def _link_in(batch, x):
     """the incoming link of the block about to run, if its producer ran as a block call and x is that call's output itself"""
     link = getattr(batch, "gate_link_in", None)
-    if (link is None or not GATE_LINKS or link.out is None or link.out is not x or not torch.is_grad_enabled()
+    if (link is None or not GATE_LINKS or link.out is None or link.out() is not x or not torch.is_grad_enabled()
             or not x.requires_grad or x.dtype != torch.float32):
         return None
     return link
@@ -191,7 +194,7 @@ def _link_out(batch, out, relu=True):
     """hand the block's output to the link its consumer will look at"""
     link = getattr(batch, "gate_link_out", None)
     if link is not None and GATE_LINKS and relu and torch.is_grad_enabled() and out.requires_grad:
-        link.out = out
+        link.out = weakref.ref(out)
         return link
     return None
 
