@@ -177,7 +177,7 @@ def lib():
             fn.argtypes = args
         # diagnostics switches of the library (integer globals), settable from the environment for A/B runs
         for env, sym in (("WEASAL_GEMM_SPLIT", "ws_gemm_split"), ("WEASAL_K4G_ROWS", "ws_kpconv_grid_rows"),
-                         ("WEASAL_NB_BUCKET", "ws_nb_bucket128"), ("WEASAL_NB_WIDE_CAPS", "ws_nb_wide_caps"), ("WEASAL_NB_MAX_BLOCKS", "ws_nb_max_blocks"), ("WEASAL_POOL_INTERLEAVE", "ws_pool_interleave"), ("WEASAL_CLOSEST_BWD_VEC", "ws_closest_bwd_vec"), ("WEASAL_POOL_SPLIT_ROWS", "ws_pool_split_rows"), ("WEASAL_K4G_INTERLEAVE", "ws_kpconv_grid_interleave"), ("WEASAL_K4_INTERLEAVE", "ws_kpconv_table_interleave"), ("WEASAL_K4GW_INTERLEAVE", "ws_kpconv_gridw_interleave"), ("WEASAL_K6_INTERLEAVE", "ws_kpconv_k6_interleave"), ("WEASAL_K3_SPLIT_ROWS", "ws_kpconv_split_rows"), ("WEASAL_K3_SPLIT_NT", "ws_kpconv_split_nt"), ("WEASAL_GEMM_LOG", "ws_gemm_log"), ("WEASAL_GEMM_STAGED", "ws_gemm_staged"), ("WEASAL_GEMM_THIN_K", "ws_gemm_thin_k"), ("WEASAL_GEMM_SHALLOW", "ws_gemm_shallow"), ("WEASAL_CONTRAST_VARIANT", "ws_contrast_variant")):
+                         ("WEASAL_NB_BUCKET", "ws_nb_bucket128"), ("WEASAL_NB_WIDE_CAPS", "ws_nb_wide_caps"), ("WEASAL_NB_MAX_BLOCKS", "ws_nb_max_blocks"), ("WEASAL_POOL_INTERLEAVE", "ws_pool_interleave"), ("WEASAL_CLOSEST_BWD_VEC", "ws_closest_bwd_vec"), ("WEASAL_POOL_SPLIT_ROWS", "ws_pool_split_rows"), ("WEASAL_POOL_UNROLL", "ws_pool_unroll"), ("WEASAL_K4G_INTERLEAVE", "ws_kpconv_grid_interleave"), ("WEASAL_K4_INTERLEAVE", "ws_kpconv_table_interleave"), ("WEASAL_K4GW_INTERLEAVE", "ws_kpconv_gridw_interleave"), ("WEASAL_K6_INTERLEAVE", "ws_kpconv_k6_interleave"), ("WEASAL_K3_SPLIT_ROWS", "ws_kpconv_split_rows"), ("WEASAL_K3_SPLIT_NT", "ws_kpconv_split_nt"), ("WEASAL_GEMM_LOG", "ws_gemm_log"), ("WEASAL_GEMM_STAGED", "ws_gemm_staged"), ("WEASAL_GEMM_THIN_K", "ws_gemm_thin_k"), ("WEASAL_GEMM_SHALLOW", "ws_gemm_shallow"), ("WEASAL_CONTRAST_VARIANT", "ws_contrast_variant")):
             if env in os.environ:
                 try:
                     C.c_int.in_dll(handle, sym).value = int(os.environ[env])

@@ -43,7 +43,7 @@ __device__ __forceinline__ void pool_groups(int64_t ngroups, int ilv, int wave, 
     }
 }
 
-template <int G, typename T, typename AT = int32_t>
+template <int G, typename T, typename AT = int32_t, int U = 4>
 __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restrict__ x, int64_t ns, int c,
                                                                 const int64_t* __restrict__ inds, int64_t nq, int h,
                                                                 T* __restrict__ out, AT* __restrict__ arg,
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restri
             const bool ok = qok && ch < c;
             float4 best = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
             int bi[4] = {0, 0, 0, 0};
-            for (int h0 = 0; h0 < h; h0 += 4) {
-                float4 v[4];
+            for (int h0 = 0; h0 < h; h0 += U) {            // U neighbour rows in flight per lane
+                float4 v[U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int col = h0 + u;
                     int64_t s = (ok && col < h) ? inds[q * h + col] : -1;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void max_pool_fwd_vec_kernel(const T* __restri
                     else if (col >= h) v[u] = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {               // first maximum wins
+                for (int u = 0; u < U; ++u) {               // first maximum wins
                     if (v[u].x > best.x) { best.x = v[u].x; bi[0] = h0 + u; }
                     if (v[u].y > best.y) { best.y = v[u].y; bi[1] = h0 + u; }
                     if (v[u].z > best.z) { best.z = v[u].z; bi[2] = h0 + u; }
@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void closest_pool_bwd_vec_kernel(const float* 
 // workgroups per XCD of the interleaved assignment (0 = contiguous chunks; A/B switch WEASAL_POOL_INTERLEAVE).  Level-0 max-pool
 // of the DALES step (71 000 x 59 rows of 512 bytes): forward 245 -> 195 us in the step, 136 -> 97 us alone (tools/pool_lab.py)
 extern "C" int ws_pool_interleave = 256;
+extern "C" int ws_pool_unroll = 8;          // neighbour rows in flight per lane of the 128-channel max-pool forward: 8 (level 0 of the DALES step: 184 -> 172 us alone) or 4
 extern "C" int ws_pool_split_rows = 8192;   // max-pools over fewer rows than this give every 256-channel chunk of a row a wave of its own (0 = never)
 static int pool_split(int64_t rows, int c)
 {
@@ -380,6 +381,7 @@ int max_pool_fwd_u8_impl(const float* x, int64_t ns, int32_t c, const int64_t* i
     if (c <= 16) max_pool_fwd_vec_kernel<4, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 16), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     else if (c <= 32) max_pool_fwd_vec_kernel<8, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 8), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     else if (c <= 64) max_pool_fwd_vec_kernel<16, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 4), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
+    else if (c <= 128 && ws_pool_unroll == 8) max_pool_fwd_vec_kernel<32, float, uint8_t, 8><<<pool_grid(ws_ceil_div(nq, 2), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     else if (c <= 128) max_pool_fwd_vec_kernel<32, float, uint8_t><<<pool_grid(ws_ceil_div(nq, 2), ilv), 256, 0, st>>>(x, ns, c, inds, nq, h, out, arg, order, ilv);
     else {
         const int sp = pool_split(nq, c);
